@@ -1,0 +1,136 @@
+/* wmf_hip.h -- C ABI of libwmf_hip.so: MI355X (gfx950) kernels for the WMF/ALS hot path.
+ *
+ * The reference (titoeb/RecModel) has no FFI or operator interface for this path: the seam is
+ * the pair of pure functions
+ *
+ *     WMF.recompute_factors(Y, C, lambda_reg)            RecModel/wmf_model.py:213-240
+ *     WMF.recompute_factors_bias(Y, C, lambda_reg, ...)  RecModel/wmf_model.py:311-351
+ *
+ * plus WMF.predict (wmf_model.py:191-211) as used by RecModel.eval_prec (base_model.py:150-179).
+ * This header declares what a ctypes / cffi binding for those functions binds.  INTEGRATION.md
+ * shows the reference-side stub.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative WMF_E* code, and
+ *     wmf_last_error() returns a message for the calling thread's last failure.
+ *   - "host" entry points take host pointers and are self-contained (own hipMalloc/copies).
+ *   - "device" entry points take device pointers and a hipStream_t passed as void*; they only
+ *     enqueue work (no allocation, no synchronisation) so a caller can keep factors resident in
+ *     HBM across half steps and put collectives between them.
+ *   - factor matrices are row-major fp32 with a leading dimension `ld` (floats), ld % 4 == 0,
+ *     ld >= f; the padding columns [f, ld) must be zero on input and are written as zero.
+ *     f = k (no bias) or k+1 (bias: column 0 is the bias, wmf_model.py:328-331).
+ *   - CSR is consumed "as stored": stored zeros contribute, duplicates are not merged
+ *     (wmf_model.py:231-239).  indptr is int64, indices int32, values fp32.
+ */
+#ifndef WMF_HIP_H
+#define WMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WMF_OK            0
+#define WMF_EINVAL       -1   /* bad argument (shape, alignment, unsupported f)           */
+#define WMF_EHIP         -2   /* a HIP runtime call failed                                */
+#define WMF_ENOMEM       -3   /* allocation failed                                        */
+#define WMF_ENUMERIC     -4   /* Gramian not positive definite / singular row system      */
+
+#define WMF_MAX_F        260  /* largest supported factor width (k = 256 + bias, padded)  */
+
+typedef struct wmf_plan wmf_plan;   /* opaque: degree-binned row schedule of one CSR matrix */
+
+/* ---- library ---------------------------------------------------------------------------- */
+const char* wmf_last_error(void);
+int  wmf_version(void);
+/* Smallest legal leading dimension for factor width f (round up to a multiple of 4). */
+int  wmf_ld_for(int f);
+
+/* ---- host-level drop-in for the operator seam -------------------------------------------- */
+/* X_new = recompute_factors[_bias](Y, C, lambda)          wmf_model.py:213-240 / 311-351
+ *   Y_host   [m, f]  row-major contiguous fp32 (bias != 0: column 0 is the fixed side's bias)
+ *   C        CSR [n, m]: indptr int64[n+1], indices int32[nnz], values fp32[nnz]
+ *   X_host   [n, f]  output, row-major contiguous fp32
+ * Runs on the current HIP device; synchronous. */
+int wmf_recompute_factors_host(const float* Y_host, int64_t m, int f, int bias,
+                               const int64_t* indptr, const int32_t* indices, const float* values,
+                               int64_t n, double lambda, float* X_host);
+
+/* ---- device-level building blocks (resident training loop) ------------------------------- */
+/* Workspace (device, caller-allocated) needed by the Gramian + factorisation step. */
+int64_t wmf_gram_workspace_bytes(int f);
+
+/* Partial Gramian of a (shard of a) factor matrix:  G_sum[f*f] (fp64, row-major) =
+ * sum_r y~_r y~_r^T over the m rows given, where y~ = y with column 0 replaced by 1 when
+ * bias != 0 (wmf_model.py:331-332).  No lambda yet: multi-GPU callers all-reduce G_sum first.
+ * wmf_model.py:215 (np.dot(Y.T, Y)). */
+int wmf_gram(const float* Y, int64_t m, int f, int ld, int bias,
+             double* G_sum, void* workspace, void* stream);
+
+/* From the (all-reduced) Gramian: A = G_sum + lambda*I = L L^T (fp64, on device) and the two
+ * fp32 transforms used by the row solve, both [f, ld] row-major, zero padded:
+ *   W_white[a][b]   = (L^-T)[a][b]     V = Y~ . W_white      (whitened fixed factors)
+ *   W_unwhite[a][b] = (L^-1)[a][b]     X = g  . W_unwhite    (back to factor space)
+ * info (device int32): 0 = ok, j > 0 = leading minor j not positive definite.
+ * Replaces the `+ lambda_reg * np.eye(...)` of wmf_model.py:215/332 and the shared part of the
+ * per-row np.linalg.solve of :239/:350. */
+int wmf_factorize(const double* G_sum, int f, int ld, double lambda,
+                  float* W_white, float* W_unwhite, int32_t* info,
+                  void* workspace, void* stream);
+
+/* out[r, :] = in~[r, :] . W  for rows [0, m), in/out [m, ld], W [f, ld].
+ * set_col0_one != 0: in~ is `in` with column 0 read as 1, and in[r,0] is copied to
+ * col0_out[r] (the fixed side's bias vector, wmf_model.py:328-331).  col0_out may be NULL. */
+int wmf_row_transform(const float* in, int64_t m, int f, int ld, const float* W,
+                      int set_col0_one, float* out, float* col0_out, void* stream);
+
+/* Degree-binned schedule for the rows of one CSR matrix (built once per matrix, host indptr). */
+int  wmf_plan_create(const int64_t* indptr_host, int64_t n, int f, wmf_plan** out);
+void wmf_plan_destroy(wmf_plan* p);
+/* Number of rows the plan routes to each kernel family: out[0]=<=16 nnz, [1]=17..32,
+ * [2]=MFMA Gramian path, [3]=general LU path. */
+int  wmf_plan_stats(const wmf_plan* p, int64_t* out4);
+
+/* The per-row normal-equation solve in whitened coordinates, for every row of the CSR:
+ *   g_u = (I + V_u^T D_u V_u)^-1 V_u^T (w_u + 1),   V_u = V[idx_u], D_u = diag(w_u)
+ * with w_u = values - bias_fixed[idx_u] when bias_fixed != NULL (wmf_model.py:343).
+ * g [n, ld]; follow with wmf_row_transform(g, W_unwhite) to obtain X_new.
+ * Restates the loop body wmf_model.py:220-239 / 337-350.  Rows without stored entries give 0.
+ * fail_count (device int32, caller zeroes): number of rows whose system was numerically singular. */
+int wmf_solve_rows(const wmf_plan* plan, const float* V, const float* bias_fixed,
+                   const int64_t* indptr, const int32_t* indices, const float* values,
+                   int64_t n, int f, int ld, float* g, int32_t* fail_count, void* stream);
+
+/* Sum over the stored, non-zero entries of a CSR "utility" matrix of (value - predict(u, i))^2
+ * and |value - predict(u, i)| -- RecModel.eval_prec (base_model.py:163-176) with WMF.predict
+ * (wmf_model.py:205-211).  The CSR has n user rows; `users` is the matching [n, ld] factor block
+ * (a multi-GPU caller passes its own user shard and the shard's CSR), `items` the full item
+ * matrix.  Stored zeros are skipped (utility_mat.nonzero(), base_model.py:163).
+ * out3 (device fp64[3]) = { sum of squares, sum of abs, count }.
+ * workspace: device, wmf_eval_workspace_bytes() bytes. */
+int64_t wmf_eval_workspace_bytes(void);
+int wmf_eval_sqerr(const float* users, const float* items, int f, int ld, int bias,
+                   const int64_t* indptr, const int32_t* indices, const float* values,
+                   int64_t n, double* out3, void* workspace, void* stream);
+
+/* out[p] = predict(users_idx[p], items_idx[p])   wmf_model.py:205-211.
+ * n_u == 1 or n_i == 1 broadcasts that index (the reference's one-user / one-item form). */
+int wmf_predict_pairs(const float* users, const float* items, int f, int ld, int bias,
+                      const int32_t* users_idx, int64_t n_u, const int32_t* items_idx, int64_t n_i,
+                      float* out, void* stream);
+
+/* g[u, :] = sum_j values[j] * V[indices[j], :]  (CSR x dense), the SpMM of the un-weighted
+ * closed form wmf_model.py:85,88 in whitened coordinates. */
+int wmf_spmm_rows(const float* V, const int64_t* indptr, const int32_t* indices, const float* values,
+                  int64_t n, int f, int ld, float* g, void* stream);
+
+/* values[i] = alpha*log(1+beta*values[i]) (mode 0) or alpha*values[i] (mode 1), in place on the
+ * device.  wmf_model.py:119-123. */
+int wmf_confidence_transform(float* values, int64_t nnz, double alpha, double beta, int mode, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WMF_HIP_H */

@@ -1,0 +1,260 @@
+// C ABI of libwmf_hip.so (include/wmf_hip.h): argument checks, the degree-binned row plan, and
+// the self-contained host-pointer entry point that replaces WMF.recompute_factors[_bias]
+// (RecModel/wmf_model.py:213-240, :311-351).
+#include "../../include/wmf_hip.h"
+#include "wmf_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void wmf_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(call)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            wmf_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? WMF_ENOMEM : WMF_EHIP;                            \
+        }                                                                                        \
+    } while (0)
+
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        wmf_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return WMF_EHIP;
+    }
+    return WMF_OK;
+}
+
+static int check_shape(int f, int ld) {
+    if (f < 1 || f > WMF_MAX_F) { wmf_set_error("factor width f=%d outside [1, %d]", f, WMF_MAX_F); return WMF_EINVAL; }
+    if (ld < f || (ld & 3)) { wmf_set_error("leading dimension ld=%d must be a multiple of 4 and >= f=%d", ld, f); return WMF_EINVAL; }
+    if (ld > 272) { wmf_set_error("leading dimension ld=%d too large", ld); return WMF_EINVAL; }
+    return WMF_OK;
+}
+
+extern "C" {
+
+const char* wmf_last_error(void) { return g_err; }
+int wmf_version(void) { return 100; }
+int wmf_ld_for(int f) { return (f + 3) & ~3; }
+
+// ---- workspace layout of gram/factorize: [partials fp32][A fp64 f x (f|1)] --------------------
+static int64_t gram_partial_bytes(int f) {
+    const int64_t nfb = (f + 15) / 16, nt = nfb * (nfb + 1) / 2;
+    return (int64_t)WMF_GRAM_MAX_WAVES * nt * 256 * (int64_t)sizeof(float);
+}
+int64_t wmf_gram_workspace_bytes(int f) {
+    if (f < 1 || f > WMF_MAX_F) return 0;
+    return gram_partial_bytes(f) + (int64_t)f * (f | 1) * (int64_t)sizeof(double) + 256;
+}
+
+int wmf_gram(const float* Y, int64_t m, int f, int ld, int bias, double* G_sum, void* workspace, void* stream) {
+    int rc = check_shape(f, ld);
+    if (rc) return rc;
+    if (!Y || !G_sum || !workspace || m < 0) { wmf_set_error("wmf_gram: null pointer or negative m"); return WMF_EINVAL; }
+    if (wmf_launch_gram(Y, m, f, ld, bias, G_sum, (float*)workspace, (hipStream_t)stream)) {
+        wmf_set_error("wmf_gram: unsupported f=%d", f);
+        return WMF_EINVAL;
+    }
+    return check_launch("wmf_gram");
+}
+
+int wmf_factorize(const double* G_sum, int f, int ld, double lambda, float* W_white, float* W_unwhite, int32_t* info,
+                  void* workspace, void* stream) {
+    int rc = check_shape(f, ld);
+    if (rc) return rc;
+    if (!G_sum || !W_white || !W_unwhite || !info || !workspace) { wmf_set_error("wmf_factorize: null pointer"); return WMF_EINVAL; }
+    double* gA = (double*)((char*)workspace + ((gram_partial_bytes(f) + 255) & ~(int64_t)255));
+    wmf_launch_factorize(G_sum, f, ld, lambda, W_white, W_unwhite, info, gA, (hipStream_t)stream);
+    return check_launch("wmf_factorize");
+}
+
+int wmf_row_transform(const float* in, int64_t m, int f, int ld, const float* W, int set_col0_one, float* out,
+                      float* col0_out, void* stream) {
+    int rc = check_shape(f, ld);
+    if (rc) return rc;
+    if (!in || !W || !out || m < 0) { wmf_set_error("wmf_row_transform: null pointer or negative m"); return WMF_EINVAL; }
+    if (wmf_launch_transform(in, m, f, ld, W, set_col0_one, out, col0_out, (hipStream_t)stream)) {
+        wmf_set_error("wmf_row_transform: unsupported f=%d", f);
+        return WMF_EINVAL;
+    }
+    return check_launch("wmf_row_transform");
+}
+
+// ---- plan ---------------------------------------------------------------------------------------
+static int bin_of(int64_t d, int f) {
+    (void)f;
+    if (d <= 16) return WMF_BIN_LOW16;
+    if (d <= 32) return WMF_BIN_LOW32;
+    return WMF_BIN_GENERAL;
+}
+
+int wmf_plan_create(const int64_t* indptr, int64_t n, int f, wmf_plan** out) {
+    if (!indptr || !out || n < 0 || n > 0x7fffffffLL) { wmf_set_error("wmf_plan_create: bad arguments"); return WMF_EINVAL; }
+    if (f < 1 || f > WMF_MAX_F) { wmf_set_error("wmf_plan_create: f=%d unsupported", f); return WMF_EINVAL; }
+    wmf_plan* p = new wmf_plan();
+    memset(p, 0, sizeof(*p));
+    p->n = n; p->f = f;
+    std::vector<int32_t> order((size_t)n);
+    int64_t start[WMF_NBINS + 1] = {0};
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t d = indptr[r + 1] - indptr[r];
+        if (d < 0) { delete p; wmf_set_error("wmf_plan_create: indptr not monotone at row %lld", (long long)r); return WMF_EINVAL; }
+        p->count[bin_of(d, f)]++;
+    }
+    for (int b = 0; b < WMF_NBINS; ++b) start[b + 1] = start[b] + p->count[b];
+    int64_t fill[WMF_NBINS];
+    for (int b = 0; b < WMF_NBINS; ++b) fill[b] = start[b];
+    for (int64_t r = 0; r < n; ++r) order[(size_t)fill[bin_of(indptr[r + 1] - indptr[r], f)]++] = (int32_t)r;
+    const size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(int32_t);
+    hipError_t e = hipMalloc((void**)&p->rows_all, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->fallback_rows, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->fallback_count, 256);
+    if (e == hipSuccess && n > 0) e = hipMemcpy(p->rows_all, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(p->fallback_count, 0, 256);
+    if (e != hipSuccess) {
+        wmf_set_error("wmf_plan_create: %s", hipGetErrorString(e));
+        wmf_plan_destroy(p);
+        return e == hipErrorOutOfMemory ? WMF_ENOMEM : WMF_EHIP;
+    }
+    for (int b = 0; b < WMF_NBINS; ++b) p->rows[b] = p->rows_all + start[b];
+    *out = p;
+    return WMF_OK;
+}
+
+void wmf_plan_destroy(wmf_plan* p) {
+    if (!p) return;
+    if (p->rows_all) (void)hipFree(p->rows_all);
+    if (p->fallback_rows) (void)hipFree(p->fallback_rows);
+    if (p->fallback_count) (void)hipFree(p->fallback_count);
+    delete p;
+}
+
+int wmf_plan_stats(const wmf_plan* p, int64_t* out4) {
+    if (!p || !out4) { wmf_set_error("wmf_plan_stats: null"); return WMF_EINVAL; }
+    for (int b = 0; b < WMF_NBINS; ++b) out4[b] = p->count[b];
+    return WMF_OK;
+}
+
+int wmf_solve_rows(const wmf_plan* plan, const float* V, const float* bias_fixed, const int64_t* indptr,
+                   const int32_t* indices, const float* values, int64_t n, int f, int ld, float* g,
+                   int32_t* fail_count, void* stream) {
+    int rc = check_shape(f, ld);
+    if (rc) return rc;
+    if (!plan || !V || !indptr || !g || !fail_count) { wmf_set_error("wmf_solve_rows: null pointer"); return WMF_EINVAL; }
+    if (plan->n != n || plan->f != f) { wmf_set_error("wmf_solve_rows: plan was built for n=%lld f=%d", (long long)plan->n, plan->f); return WMF_EINVAL; }
+    if (n == 0) return WMF_OK;
+    const int lrc = wmf_launch_solve(plan, V, bias_fixed, indptr, indices, values, f, ld, g, fail_count, (hipStream_t)stream);
+    if (lrc == -2) { wmf_set_error("wmf_solve_rows: hipMemsetAsync failed"); return WMF_EHIP; }
+    if (lrc) { wmf_set_error("wmf_solve_rows: rows with more than 32 stored entries need f <= 144 in this build (f=%d)", f); return WMF_EINVAL; }
+    return check_launch("wmf_solve_rows");
+}
+
+int64_t wmf_eval_workspace_bytes(void) { return (int64_t)WMF_EVAL_MAX_BLOCKS * 3 * sizeof(double); }
+
+int wmf_eval_sqerr(const float* users, const float* items, int f, int ld, int bias, const int64_t* indptr,
+                   const int32_t* indices, const float* values, int64_t n, double* out3, void* workspace, void* stream) {
+    int rc = check_shape(f, ld);
+    if (rc) return rc;
+    if (!users || !items || !indptr || !out3 || !workspace || n < 0) { wmf_set_error("wmf_eval_sqerr: null pointer"); return WMF_EINVAL; }
+    wmf_launch_eval(users, items, f, ld, bias, indptr, indices, values, n, out3, (double*)workspace, (hipStream_t)stream);
+    return check_launch("wmf_eval_sqerr");
+}
+
+int wmf_predict_pairs(const float* users, const float* items, int f, int ld, int bias, const int32_t* users_idx,
+                      int64_t n_u, const int32_t* items_idx, int64_t n_i, float* out, void* stream) {
+    int rc = check_shape(f, ld);
+    if (rc) return rc;
+    if (!users || !items || !users_idx || !items_idx || !out) { wmf_set_error("wmf_predict_pairs: null pointer"); return WMF_EINVAL; }
+    if (n_u != n_i && n_u != 1 && n_i != 1) {
+        wmf_set_error("users and items need to have the same length or only one user / item needs to be provided.");
+        return WMF_EINVAL;
+    }
+    wmf_launch_predict(users, items, f, ld, bias, users_idx, n_u, items_idx, n_i, out, (hipStream_t)stream);
+    return check_launch("wmf_predict_pairs");
+}
+
+int wmf_spmm_rows(const float* V, const int64_t* indptr, const int32_t* indices, const float* values, int64_t n, int f,
+                  int ld, float* g, void* stream) {
+    int rc = check_shape(f, ld);
+    if (rc) return rc;
+    if (!V || !indptr || !g || n < 0) { wmf_set_error("wmf_spmm_rows: null pointer"); return WMF_EINVAL; }
+    wmf_launch_spmm(V, indptr, indices, values, n, ld, g, (hipStream_t)stream);
+    return check_launch("wmf_spmm_rows");
+}
+
+int wmf_confidence_transform(float* values, int64_t nnz, double alpha, double beta, int mode, void* stream) {
+    if ((!values && nnz > 0) || nnz < 0 || (mode != 0 && mode != 1)) { wmf_set_error("wmf_confidence_transform: bad arguments"); return WMF_EINVAL; }
+    wmf_launch_confidence(values, nnz, alpha, beta, mode, (hipStream_t)stream);
+    return check_launch("wmf_confidence_transform");
+}
+
+// ---- host-level drop-in -------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : -1; }
+};
+
+int wmf_recompute_factors_host(const float* Y_host, int64_t m, int f, int bias, const int64_t* indptr,
+                               const int32_t* indices, const float* values, int64_t n, double lambda, float* X_host) {
+    if (!Y_host || !indptr || !X_host || m < 1 || n < 0 || f < 1 || f > WMF_MAX_F) {
+        wmf_set_error("wmf_recompute_factors_host: bad arguments");
+        return WMF_EINVAL;
+    }
+    const int ld = wmf_ld_for(f);
+    const int64_t nnz = indptr[n];
+    if (nnz > 0 && (!indices || !values)) { wmf_set_error("wmf_recompute_factors_host: null CSR arrays"); return WMF_EINVAL; }
+    for (int64_t j = 0; j < nnz; ++j)
+        if (indices[j] < 0 || indices[j] >= m) { wmf_set_error("column index %d out of range at entry %lld", indices[j], (long long)j); return WMF_EINVAL; }
+    DevBuf dY, dV, dG, dWw, dWu, dInfo, dWs, dBias, dPtr, dIdx, dVal, dg, dX, dFail;
+    const size_t fac_m = (size_t)m * ld * 4, fac_n = (size_t)(n > 0 ? n : 1) * ld * 4;
+    if (dY.alloc(fac_m) || dV.alloc(fac_m) || dG.alloc((size_t)f * f * 8) || dWw.alloc((size_t)f * ld * 4) ||
+        dWu.alloc((size_t)f * ld * 4) || dInfo.alloc(16) || dWs.alloc((size_t)wmf_gram_workspace_bytes(f)) ||
+        dBias.alloc((size_t)m * 4) || dPtr.alloc((size_t)(n + 1) * 8) || dIdx.alloc((size_t)nnz * 4) ||
+        dVal.alloc((size_t)nnz * 4) || dg.alloc(fac_n) || dX.alloc(fac_n) || dFail.alloc(16)) {
+        wmf_set_error("wmf_recompute_factors_host: device allocation failed");
+        return WMF_ENOMEM;
+    }
+    HIP_TRY(hipMemset(dY.p, 0, fac_m));
+    HIP_TRY(hipMemcpy2D(dY.p, (size_t)ld * 4, Y_host, (size_t)f * 4, (size_t)f * 4, (size_t)m, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dPtr.p, indptr, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        HIP_TRY(hipMemcpy(dIdx.p, indices, (size_t)nnz * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dVal.p, values, (size_t)nnz * 4, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemset(dFail.p, 0, 16));
+    wmf_plan* plan = nullptr;
+    int rc = wmf_plan_create(indptr, n, f, &plan);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    rc = wmf_gram((const float*)dY.p, m, f, ld, bias, (double*)dG.p, dWs.p, st);
+    if (!rc) rc = wmf_factorize((const double*)dG.p, f, ld, lambda, (float*)dWw.p, (float*)dWu.p, (int32_t*)dInfo.p, dWs.p, st);
+    if (!rc) rc = wmf_row_transform((const float*)dY.p, m, f, ld, (const float*)dWw.p, bias, (float*)dV.p, bias ? (float*)dBias.p : nullptr, st);
+    if (!rc) rc = wmf_solve_rows(plan, (const float*)dV.p, bias ? (const float*)dBias.p : nullptr, (const int64_t*)dPtr.p,
+                                 (const int32_t*)dIdx.p, (const float*)dVal.p, n, f, ld, (float*)dg.p, (int32_t*)dFail.p, st);
+    if (!rc) rc = wmf_row_transform((const float*)dg.p, n, f, ld, (const float*)dWu.p, 0, (float*)dX.p, nullptr, st);
+    wmf_plan_destroy(plan);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    int32_t info = 0, fail = 0;
+    HIP_TRY(hipMemcpy(&info, dInfo.p, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&fail, dFail.p, 4, hipMemcpyDeviceToHost));
+    if (info) { wmf_set_error("Gramian + lambda*I is not positive definite (leading minor %d)", info); return WMF_ENUMERIC; }
+    if (n > 0) HIP_TRY(hipMemcpy2D(X_host, (size_t)f * 4, dX.p, (size_t)ld * 4, (size_t)f * 4, (size_t)n, hipMemcpyDeviceToHost));
+    if (fail) { wmf_set_error("%d row systems were singular", fail); return WMF_ENUMERIC; }
+    return WMF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// Shared device helpers for the WMF/ALS kernels (gfx950 only: 64-wide waves, f32 MFMA, DPP).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] * B[k][j], i,j in [0,16), k in [0,4).
+//   lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15];
+//   lane l holds    D[4 * (l >> 4) + reg][l & 15] in acc[reg].
+// Exact f32 (an fma chain in k order), same rate as the f32 VALU peak.
+#define WMF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int CTRL>
+__device__ __forceinline__ float wmf_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+
+// Sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15); every lane of the row gets the total.
+__device__ __forceinline__ float wmf_row16_sum(float v) {
+    v += wmf_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += wmf_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += wmf_dpp<0x141>(v);   // row_half_mirror
+    v += wmf_dpp<0x140>(v);   // row_mirror
+    return v;
+}
+
+__device__ __forceinline__ double wmf_wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+static inline int wmf_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,340 @@
+// Dense shared-work kernels of one ALS half step (gfx950):
+//   gram       G_sum = Y~^T Y~                      f32 MFMA, fp64 cross-wave reduction
+//   factorize  G_sum + lambda I = L L^T (fp64), W_white = L^-T, W_unwhite = L^-1 (fp32 out)
+//   transform  out = in~ . W                        f32 MFMA, W staged in LDS
+// Reference arithmetic: RecModel/wmf_model.py:215 and :328-332 (Gramian of the fixed side, bias
+// column forced to one), and the shared part of the per-row solve (:239, :350).
+#include "wmf_common.h"
+#include "wmf_internal.h"
+
+// ------------------------------------------------------------------------------------------ gram
+// One wave per workgroup.  A wave walks a contiguous range of 4-row steps; at each step lane
+// (r = l & 15, q = l >> 4) loads Y~[4s + q][16 fb + r] for every 16-column feature block fb.  The
+// same registers are both MFMA operands: tile(bi, bj) += frag[bi]^T frag[bj].  Tiles with
+// bi <= bj only.  Each wave writes its partial tiles to `partial`; gram_reduce sums them in fp64.
+template <int NFB, int NSPLIT, int S>
+__device__ __forceinline__ void gram_body(const float* __restrict__ Y, int64_t m, int f, int ld, int bias,
+                                          float* __restrict__ partial, int64_t step_lo, int64_t step_hi) {
+    constexpr int NT = NFB * (NFB + 1) / 2;
+    constexpr int NACC = (NT + NSPLIT - 1) / NSPLIT;
+    const int lane = threadIdx.x;
+    const int r = lane & 15, q = lane >> 4;
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t s = step_lo; s < step_hi; ++s) {
+        const int64_t row = 4 * s + q;
+        const bool rok = row < m;
+        const float* yrow = Y + row * (int64_t)ld;
+        float frag[NFB];
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+            const int col = 16 * fb + r;
+            float v = (rok && col < f) ? yrow[col] : 0.f;
+            if (bias && col == 0 && rok) v = 1.f;
+            frag[fb] = v;
+        }
+        int t = 0;
+#pragma unroll
+        for (int bi = 0; bi < NFB; ++bi) {
+#pragma unroll
+            for (int bj = bi; bj < NFB; ++bj, ++t) {
+                if (t % NSPLIT == S) acc[t / NSPLIT] = WMF_MFMA16(frag[bi], frag[bj], acc[t / NSPLIT]);
+            }
+        }
+    }
+    // partial layout: [wave][tile][reg][lane]
+    float* out = partial + (int64_t)blockIdx.x * NT * 256;
+    int t = 0;
+#pragma unroll
+    for (int bi = 0; bi < NFB; ++bi) {
+#pragma unroll
+        for (int bj = bi; bj < NFB; ++bj, ++t) {
+            if (t % NSPLIT == S) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) out[(t * 4 + reg) * 64 + lane] = acc[t / NSPLIT][reg];
+            }
+        }
+    }
+}
+
+template <int NFB, int NSPLIT>
+__global__ __launch_bounds__(64) void gram_kernel(const float* __restrict__ Y, int64_t m, int f, int ld, int bias,
+                                                  float* __restrict__ partial, int64_t steps_per_wave) {
+    const int64_t nsteps = (m + 3) / 4;
+    int64_t lo = (int64_t)blockIdx.x * steps_per_wave;
+    int64_t hi = lo + steps_per_wave;
+    if (hi > nsteps) hi = nsteps;
+    if (lo > hi) lo = hi;
+    if constexpr (NSPLIT == 1) {
+        gram_body<NFB, 1, 0>(Y, m, f, ld, bias, partial, lo, hi);
+    } else {
+        switch (blockIdx.y) {
+            case 0: gram_body<NFB, NSPLIT, 0>(Y, m, f, ld, bias, partial, lo, hi); break;
+            case 1: gram_body<NFB, NSPLIT, 1>(Y, m, f, ld, bias, partial, lo, hi); break;
+            case 2: gram_body<NFB, NSPLIT, 2>(Y, m, f, ld, bias, partial, lo, hi); break;
+            default: gram_body<NFB, NSPLIT, 3>(Y, m, f, ld, bias, partial, lo, hi); break;
+        }
+    }
+}
+
+// G_sum[i][j] (fp64) = sum over waves of the partial tile element; symmetric fill.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ partial, int nwaves, int f, int nfb,
+                                                          double* __restrict__ G) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= f * f) return;
+    int i = e / f, j = e % f;
+    if (i > j) { int tmp = i; i = j; j = tmp; }
+    const int bi = i >> 4, bj = j >> 4, ri = i & 15, cj = j & 15;
+    // index of tile (bi, bj), bi <= bj, in row-major enumeration of the upper triangle
+    const int t = bi * nfb - (bi * (bi - 1)) / 2 + (bj - bi);
+    const int lane = cj + 16 * (ri >> 2), reg = ri & 3;
+    const int nt = nfb * (nfb + 1) / 2;
+    const float* p = partial + ((int64_t)t * 4 + reg) * 64 + lane;
+    double s = 0.0;
+    for (int w = 0; w < nwaves; ++w) s += (double)p[(int64_t)w * nt * 256];
+    G[e] = s;
+}
+
+template <int NFB>
+static int launch_gram_nfb(const float* Y, int64_t m, int f, int ld, int bias, float* partial, int nwaves,
+                           hipStream_t st) {
+    const int64_t nsteps = (m + 3) / 4;
+    const int64_t spw = (nsteps + nwaves - 1) / nwaves;
+    if constexpr (NFB <= 9) {
+        hipLaunchKernelGGL((gram_kernel<NFB, 1>), dim3(nwaves), dim3(64), 0, st, Y, m, f, ld, bias, partial, spw);
+    } else {
+        hipLaunchKernelGGL((gram_kernel<NFB, 4>), dim3(nwaves, 4), dim3(64), 0, st, Y, m, f, ld, bias, partial, spw);
+    }
+    return 0;
+}
+
+int wmf_gram_nwaves(int64_t m) {
+    int64_t nsteps = (m + 3) / 4;
+    int64_t want = (nsteps + 63) / 64;     // at least 64 steps (256 rows) per wave
+    if (want < 1) want = 1;
+    if (want > WMF_GRAM_MAX_WAVES) want = WMF_GRAM_MAX_WAVES;
+    return (int)want;
+}
+
+int wmf_launch_gram(const float* Y, int64_t m, int f, int ld, int bias, double* G_sum, float* partial, hipStream_t st) {
+    const int nfb = (f + 15) / 16;
+    const int nwaves = wmf_gram_nwaves(m);
+    switch (nfb) {
+#define C(N) case N: launch_gram_nfb<N>(Y, m, f, ld, bias, partial, nwaves, st); break;
+        C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)
+#undef C
+        default: return -1;
+    }
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((f * f + 255) / 256), dim3(256), 0, st, partial, nwaves, f, nfb, G_sum);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- factorize
+// Single workgroup.  A (fp64, row stride lda odd) lives in LDS when it fits, else in the global
+// workspace.  Right-looking Cholesky with one thread per trailing column, then the in-place
+// inverse of the lower triangle (column by column from the last), then the two fp32 outputs.
+__global__ __launch_bounds__(256) void factorize_kernel(const double* __restrict__ G, int f, int ld, double lambda,
+                                                        float* __restrict__ Wwhite, float* __restrict__ Wunwhite,
+                                                        int32_t* __restrict__ info, double* __restrict__ gA, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* A = use_lds ? reinterpret_cast<double*>(smem_raw) : gA;
+    const int lda = f | 1;
+    const int t = threadIdx.x;
+    // the flag lives behind the matrix in the dynamic region (no static LDS in front of it)
+    volatile int& s_fail = *reinterpret_cast<volatile int*>(smem_raw + (use_lds ? (size_t)f * lda * sizeof(double) : 0));
+    if (t == 0) s_fail = 0;
+    for (int e = t; e < f * f; e += 256) {
+        const int i = e / f, j = e % f;
+        A[i * lda + j] = G[e] + (i == j ? lambda : 0.0);
+    }
+    __syncthreads();
+    // ---- Cholesky (lower).  Column k: scale, then thread j owns trailing column j.
+    for (int k = 0; k < f; ++k) {
+        const double dk = A[k * lda + k];
+        if (!(dk > 0.0)) {            // same value seen by every thread: uniform exit
+            if (t == 0) s_fail = k + 1;
+            break;
+        }
+        const double sk = sqrt(dk), inv = 1.0 / sk;
+        __syncthreads();              // everyone has read A[k][k] before it is overwritten
+        for (int i = k + 1 + t; i < f; i += 256) A[i * lda + k] *= inv;
+        if (t == 0) A[k * lda + k] = sk;
+        __syncthreads();
+        for (int j = k + 1 + t; j < f; j += 256) {
+            const double ljk = A[j * lda + k];
+            for (int i = j; i < f; ++i) A[i * lda + j] -= A[i * lda + k] * ljk;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    const int fail = s_fail;
+    if (t == 0) *info = fail;
+    if (fail) {                       // poison nothing: write zero transforms so downstream stays finite
+        for (int e = t; e < f * ld; e += 256) { Wwhite[e] = 0.f; Wunwhite[e] = 0.f; }
+        return;
+    }
+    // ---- in-place inverse of lower-triangular L (unblocked trti2, lower, non-unit):
+    // for j = f-1 .. 0:  X[j][j] = 1/L[j][j];  X[i][j] = -X[j][j] * sum_{k=j+1..i} X[i][k] L[k][j]  (i > j)
+    for (int j = f - 1; j >= 0; --j) {
+        const double xjj = 1.0 / A[j * lda + j];
+        double y0 = 0.0;
+        const int i0 = j + 1 + t;      // f <= 260 and 256 threads: at most 2 rows per thread
+        const int i1 = i0 + 256;
+        double y1 = 0.0;
+        if (i0 < f) for (int k = j + 1; k <= i0; ++k) y0 += A[i0 * lda + k] * A[k * lda + j];
+        if (i1 < f) for (int k = j + 1; k <= i1; ++k) y1 += A[i1 * lda + k] * A[k * lda + j];
+        __syncthreads();              // all reads of column j done before it is overwritten
+        if (i0 < f) A[i0 * lda + j] = -xjj * y0;
+        if (i1 < f) A[i1 * lda + j] = -xjj * y1;
+        if (t == 0) A[j * lda + j] = xjj;
+        __syncthreads();
+    }
+    // ---- outputs: Wunwhite[a][b] = Linv[a][b] (a >= b), Wwhite[a][b] = Linv[b][a] (b >= a)
+    for (int e = t; e < f * ld; e += 256) {
+        const int a = e / ld, b = e % ld;
+        float wu = 0.f, ww = 0.f;
+        if (b < f) {
+            if (a >= b) wu = (float)A[a * lda + b];
+            if (b >= a) ww = (float)A[b * lda + a];
+        }
+        Wunwhite[e] = wu;
+        Wwhite[e] = ww;
+    }
+}
+
+int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, float* Wwhite, float* Wunwhite,
+                         int32_t* info, double* gA, hipStream_t st) {
+    const int lda = f | 1;
+    const size_t bytes = (size_t)f * lda * sizeof(double);
+    const int use_lds = bytes <= 150 * 1024;
+    static bool attr_set = false;
+    if (use_lds && !attr_set) {
+        (void)hipFuncSetAttribute((const void*)factorize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024 + 16);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(factorize_kernel, dim3(1), dim3(256), (use_lds ? bytes : 0) + 16, st, G_sum, f, ld, lambda, Wwhite,
+                       Wunwhite, info, gA, use_lds);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- transform
+// out[row][:] = in~[row][:] . W.  A wave owns 16-row blocks.  Lane (r = l & 15, q = l >> 4) loads
+// 16-byte pieces in[row0 + r][16 t + 4 q .. +3]; its element e is the A operand of MFMA step
+// (t, e), whose k slot q then means k = 16 t + 4 q + e; the B operand is W[k][16 nb + r] read from
+// the LDS copy of W (row stride ldw = 4 mod 8 dwords keeps the two k rows of a 32-lane half on
+// different banks).  The sum over k is order independent, so this k permutation is free.
+template <int NFB, bool W_IN_LDS>
+__global__ __launch_bounds__(512) void transform_kernel(const float* __restrict__ in, int64_t m, int f, int ld,
+                                                        const float* __restrict__ W, int set_col0_one,
+                                                        float* __restrict__ out, float* __restrict__ col0_out,
+                                                        int64_t nblocks16) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Wl = reinterpret_cast<float*>(smem_raw);
+    constexpr int KP = 16 * NFB;          // padded K (rows of W) and padded N (cols of W)
+    constexpr int LDW = KP + 4;           // 4 mod 8 since KP is a multiple of 16
+    const int tid = threadIdx.x;
+    if constexpr (W_IN_LDS) {
+        for (int e = tid; e < KP * LDW; e += 512) {
+            const int a = e / LDW, b = e % LDW;
+            Wl[e] = (a < f && b < f) ? W[a * ld + b] : 0.f;
+        }
+        __syncthreads();
+    }
+    const int lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int nch = ld >> 2;
+    for (int64_t blk = (int64_t)blockIdx.x * 8 + wv; blk < nblocks16; blk += (int64_t)gridDim.x * 8) {
+        const int64_t row = blk * 16 + r;
+        const bool rok = row < m;
+        const float4* irow = reinterpret_cast<const float4*>(in + row * (int64_t)ld);
+        f32x4 acc[NFB];
+#pragma unroll
+        for (int nb = 0; nb < NFB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rok && q < nch) xn = irow[q];
+#pragma unroll 1
+        for (int t = 0; t < NFB; ++t) {
+            const int c = 4 * t + q;                 // 16-byte piece index within the row
+            const float4 x = xn;
+            if (t + 1 < NFB) {                       // prefetch the next piece
+                xn = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rok && c + 4 < nch) xn = irow[c + 4];
+            }
+            const int k0 = 4 * c;
+            float xe[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (k0 + e >= f) xe[e] = 0.f;
+            if (set_col0_one && c == 0) {
+                if (rok && col0_out) col0_out[row] = xe[0];
+                xe[0] = rok ? 1.f : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + e;
+#pragma unroll
+                for (int nb = 0; nb < NFB; ++nb) {
+                    float b;
+                    if constexpr (W_IN_LDS) {
+                        b = Wl[k * LDW + 16 * nb + r];
+                    } else {
+                        const int col = 16 * nb + r;
+                        b = (k < f && col < f) ? W[k * ld + col] : 0.f;
+                    }
+                    acc[nb] = WMF_MFMA16(xe[e], b, acc[nb]);
+                }
+            }
+        }
+        // acc[nb][reg] = out[blk*16 + 4q + reg][16 nb + r]
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t orow = blk * 16 + 4 * q + reg;
+            if (orow < m) {
+                float* o = out + orow * (int64_t)ld;
+#pragma unroll
+                for (int nb = 0; nb < NFB; ++nb) {
+                    const int col = 16 * nb + r;
+                    if (col < ld) o[col] = acc[nb][reg];
+                }
+            }
+        }
+    }
+}
+
+template <int NFB>
+static void launch_transform_nfb(const float* in, int64_t m, int f, int ld, const float* W, int set_col0_one, float* out,
+                                 float* col0_out, hipStream_t st) {
+    constexpr int KP = 16 * NFB, LDW = KP + 4;
+    constexpr size_t lds = (size_t)KP * LDW * 4;
+    const int64_t nblk = (m + 15) / 16;
+    int64_t grid = (nblk + 7) / 8;
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    if constexpr (lds <= 150 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)transform_kernel<NFB, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((transform_kernel<NFB, true>), dim3((unsigned)grid), dim3(512), lds, st, in, m, f, ld, W,
+                           set_col0_one, out, col0_out, nblk);
+    } else {
+        hipLaunchKernelGGL((transform_kernel<NFB, false>), dim3((unsigned)grid), dim3(512), 0, st, in, m, f, ld, W,
+                           set_col0_one, out, col0_out, nblk);
+    }
+}
+
+int wmf_launch_transform(const float* in, int64_t m, int f, int ld, const float* W, int set_col0_one, float* out,
+                         float* col0_out, hipStream_t st) {
+    if (m <= 0) return 0;
+    const int nfb = (f + 15) / 16;
+    switch (nfb) {
+#define C(N) case N: launch_transform_nfb<N>(in, m, f, ld, W, set_col0_one, out, col0_out, st); break;
+        C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)
+#undef C
+        default: return -1;
+    }
+    return 0;
+}

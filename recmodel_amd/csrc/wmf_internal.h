@@ -1,0 +1,41 @@
+// Internal launcher declarations shared by the .hip translation units of libwmf_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WMF_GRAM_MAX_WAVES 1024
+#define WMF_EVAL_MAX_BLOCKS 2048
+
+// row-degree bins of a plan
+enum { WMF_BIN_LOW16 = 0, WMF_BIN_LOW32 = 1, WMF_BIN_MFMA = 2, WMF_BIN_GENERAL = 3, WMF_NBINS = 4 };
+
+struct wmf_plan {
+    int64_t n;                 // rows
+    int f;
+    int64_t count[WMF_NBINS];  // rows per bin
+    int32_t* rows[WMF_NBINS];  // device: row ids of each bin (slices of rows_all)
+    int32_t* rows_all;         // device: n row ids grouped by bin
+    int32_t* fallback_rows;    // device: n slots, rows bounced to the general kernel at run time
+    int32_t* fallback_count;   // device: 1 counter
+};
+
+int wmf_gram_nwaves(int64_t m);
+int wmf_launch_gram(const float* Y, int64_t m, int f, int ld, int bias, double* G_sum, float* partial, hipStream_t st);
+int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, float* Wwhite, float* Wunwhite,
+                         int32_t* info, double* gA, hipStream_t st);
+int wmf_launch_transform(const float* in, int64_t m, int f, int ld, const float* W, int set_col0_one, float* out,
+                         float* col0_out, hipStream_t st);
+
+int wmf_launch_solve(const wmf_plan* plan, const float* V, const float* bias_fixed, const int64_t* indptr,
+                     const int32_t* indices, const float* values, int f, int ld, float* g, int32_t* fail_count,
+                     hipStream_t st);
+int wmf_launch_spmm(const float* V, const int64_t* indptr, const int32_t* indices, const float* values, int64_t n,
+                    int ld, float* g, hipStream_t st);
+int wmf_launch_eval(const float* users, const float* items, int f, int ld, int bias, const int64_t* indptr,
+                    const int32_t* indices, const float* values, int64_t n, double* out3, double* partial,
+                    hipStream_t st);
+int wmf_launch_predict(const float* users, const float* items, int f, int ld, int bias, const int32_t* ui, int64_t n_u,
+                       const int32_t* ii, int64_t n_i, float* out, hipStream_t st);
+int wmf_launch_confidence(float* values, int64_t nnz, double alpha, double beta, int mode, hipStream_t st);
+
+void wmf_set_error(const char* fmt, ...);

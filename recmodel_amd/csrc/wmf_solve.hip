@@ -1,0 +1,371 @@
+// Per-row normal-equation solve of one ALS half step, in whitened coordinates (gfx950).
+//
+// Reference loop body: RecModel/wmf_model.py:220-239 (no bias) / :337-350 (bias):
+//     A_u = G + U^T diag(w) U,  b_u = (w + 1)^T U,  x_u = solve(A_u, b_u),  U = Y[idx_u]
+// With G = L L^T and V = Y~ L^-T (wmf_dense.hip) this is  x_u = L^-T g_u  with
+//     g_u = (I + V_u^T D V_u)^-1 V_u^T p,           p = w + 1, D = diag(w)      ("direct", f x f)
+//         = V_u^T (I + D S)^-1 p,  S = V_u V_u^T                                 ("low rank", d x d)
+// The two forms are algebraically identical (push-through identity); the second costs O(d^2 f)
+// instead of O(d f^2 + f^3) and is used for rows with few stored entries, which is most of them.
+// Only V is gathered: one 4f-byte row per stored entry, the same bytes the reference's Y[idx] reads.
+//
+// Kernels
+//   solve_low<NCH, 1>   d <= 16, one wave per row: S by f32 MFMA straight from global loads,
+//   solve_low<NCH, 2>   d <= 32   Gauss-Jordan on (I + D S) across the wave, g by DPP row sums.
+//   solve_general<NFB>  any d, any sign of w: f x f system in LDS, LU with partial pivoting
+//                       (the reference's np.linalg.solve is LAPACK gesv = the same algorithm).
+#include "wmf_common.h"
+#include "wmf_internal.h"
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// ------------------------------------------------------------------------------ low-degree rows
+// Lane (r = l & 15, q = l >> 4).  Stored entry j of the row is handled by the four lanes with
+// r == j (set A) or r == j - 16 (set B, NSETS == 2).  Each lane loads 16-byte pieces
+// V[idx][16 t + 4 q .. +3]; element e of piece t is the MFMA operand of step (t, e) for k slot q.
+// Because S = V_u V_u^T, the same register is the A and the B operand.
+template <int NCH, int NSETS>
+__global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restrict__ rows, int64_t count,
+                                                        const float* __restrict__ V, const float* __restrict__ biasv,
+                                                        const int64_t* __restrict__ indptr,
+                                                        const int32_t* __restrict__ indices,
+                                                        const float* __restrict__ vals, int ld, float* __restrict__ g,
+                                                        int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= count) return;                       // whole wave exits together
+    const int u = rows[wid];
+    const int64_t lo = indptr[u];
+    const int d = (int)(indptr[u + 1] - lo);
+    const int r = lane & 15, q = lane >> 4;
+    const int nch = ld >> 2;
+
+    float w[NSETS], p[NSETS];
+    float4 x[NSETS][NCH];
+    bool neg = false;
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s) {
+        const int j = r + 16 * s;
+        const bool act = j < d;
+        int idx = 0;
+        float wj = 0.f;
+        if (act) {
+            idx = indices[lo + j];
+            wj = vals[lo + j];
+            if (biasv) wj -= biasv[idx];
+            if (!(wj >= 0.f)) neg = true;           // negative or NaN weight: needs pivoting
+        }
+        w[s] = wj;
+        p[s] = wj + 1.f;
+        const float4* vrow = reinterpret_cast<const float4*>(V + (int64_t)idx * ld);
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            const int c = 4 * t + q;
+            x[s][t] = (act && c < nch) ? vrow[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (__any(neg)) {                               // wave-uniform: bounce the row to the LU kernel
+        if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;
+        return;
+    }
+
+    // ---- S blocks by MFMA.  m[s][c*4 + reg] = M[row j = r + 16 s][col 16 c + 4 q + reg],
+    //      M = I + D S.  acc layout: D[4q + reg][r]; S symmetric, so tile(a=x[c], b=x[s]) holds
+    //      S[set c row 4q+reg][set s row r] = S[set s row r][set c row 4q+reg].
+    float m[NSETS][NSETS * 4];
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s) {
+#pragma unroll
+        for (int c = 0; c < NSETS; ++c) {
+            f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                a0 = WMF_MFMA16(x[c][t].x, x[s][t].x, a0);
+                a1 = WMF_MFMA16(x[c][t].y, x[s][t].y, a1);
+                a0 = WMF_MFMA16(x[c][t].z, x[s][t].z, a0);
+                a1 = WMF_MFMA16(x[c][t].w, x[s][t].w, a1);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float sij = a0[reg] + a1[reg];
+                const float diag = (s == c && r == 4 * q + reg) ? 1.f : 0.f;
+                m[s][c * 4 + reg] = w[s] * sij + diag;
+            }
+        }
+    }
+
+    // ---- Gauss-Jordan without pivoting on M (row-scaled SPD when w >= 0: pivots >= 1).
+    //      Row j is spread over the 4 lanes (r, q = 0..3); column k lives in lanes q = (k & 15) >> 2,
+    //      register (k >> 4) * 4 + (k & 3).  After the sweep M = I and p = M^-1 p = c.
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 16 * NSETS; ++k) {
+        if (k < d) {                                // d is wave-uniform
+            const int ks = k >> 4, kk = k & 15, kq = kk >> 2, kreg = ks * 4 + (kk & 3);
+            const float piv = readlane_f(m[ks][kreg], kk + 16 * kq);
+            if (!(piv > 0.25f)) bad = true;
+            const float inv = 1.f / piv;
+            float pr[NSETS * 4];
+#pragma unroll
+            for (int c = 0; c < NSETS * 4; ++c) pr[c] = __shfl(m[ks][c], (lane & 48) | kk) * inv;
+            const float pk = readlane_f(p[ks], kk) * inv;
+#pragma unroll
+            for (int s = 0; s < NSETS; ++s) {
+                const float fk = __shfl(m[s][kreg], r + 16 * kq);
+                const bool is_piv = (s == ks) && (r == kk);
+#pragma unroll
+                for (int c = 0; c < NSETS * 4; ++c) m[s][c] = is_piv ? pr[c] : (m[s][c] - fk * pr[c]);
+                p[s] = is_piv ? pk : (p[s] - fk * pk);
+            }
+        }
+    }
+    if (bad) {                                      // uniform (piv is a scalar)
+        if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;
+        return;
+    }
+
+    // ---- g = V_u^T c: scale own pieces by c_j, sum over the 16 lanes of the DPP row, store.
+    float4* grow = reinterpret_cast<float4*>(g + (int64_t)u * ld);
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+        float4 y = make_float4(p[0] * x[0][t].x, p[0] * x[0][t].y, p[0] * x[0][t].z, p[0] * x[0][t].w);
+        if constexpr (NSETS == 2) {
+            y.x += p[1] * x[1][t].x; y.y += p[1] * x[1][t].y; y.z += p[1] * x[1][t].z; y.w += p[1] * x[1][t].w;
+        }
+        y.x = wmf_row16_sum(y.x); y.y = wmf_row16_sum(y.y); y.z = wmf_row16_sum(y.z); y.w = wmf_row16_sum(y.w);
+        const int c = 4 * t + q;
+        if (r == 0 && c < nch) grow[c] = y;
+    }
+}
+
+// ---------------------------------------------------------------------------------- general rows
+// One 256-thread workgroup per row.  Thread (ty, tx) = (tid >> 4, tid & 15) accumulates the
+// NFB x NFB register block B[ty + 16 i][tx + 16 j] of  B = I + V_u^T D V_u  over the row's
+// entries, staged RC at a time through LDS; then LU with partial pivoting in LDS.
+template <int NFB>
+__global__ __launch_bounds__(256) void solve_general_kernel(const int32_t* __restrict__ rows, int64_t count,
+                                                            const int32_t* __restrict__ count_ptr,
+                                                            const float* __restrict__ V, const float* __restrict__ biasv,
+                                                            const int64_t* __restrict__ indptr,
+                                                            const int32_t* __restrict__ indices,
+                                                            const float* __restrict__ vals, int f, int ld,
+                                                            float* __restrict__ g, int32_t* __restrict__ fail_count) {
+    constexpr int FP = 16 * NFB;
+    constexpr int LDV = FP + 4;          // staging row stride (floats), keeps 16-byte alignment
+    constexpr int LDB = FP + 1;          // odd: conflict-free column walks
+    constexpr int RC = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Vs = reinterpret_cast<float*>(smem_raw);            // [RC][LDV]
+    float* ws = Vs + RC * LDV;                                  // [RC] weights
+    float* rhs = ws + RC;                                       // [FP]
+    float* red = rhs + FP;                                      // [8] reduction scratch
+    float* B = red + 8;                                         // [FP][LDB]
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int nch = ld >> 2;
+    const int64_t total = count_ptr ? (int64_t)*count_ptr : count;
+
+    for (int64_t it = blockIdx.x; it < total; it += gridDim.x) {
+        const int u = rows[it];
+        const int64_t lo = indptr[u];
+        const int d = (int)(indptr[u + 1] - lo);
+        float acc[NFB][NFB];
+#pragma unroll
+        for (int i = 0; i < NFB; ++i)
+#pragma unroll
+            for (int j = 0; j < NFB; ++j) acc[i][j] = 0.f;
+        float racc = 0.f;
+        __syncthreads();                                        // previous row's LDS use is over
+        for (int e = tid; e < RC * LDV; e += 256) Vs[e] = 0.f;  // zero incl. columns [ld, FP)
+        for (int base = 0; base < d; base += RC) {
+            const int nrow = min(RC, d - base);
+            __syncthreads();
+            // stage nrow gathered rows (16-byte pieces) and their weights
+            for (int e = tid; e < nrow * nch; e += 256) {
+                const int j = e / nch, c = e % nch;
+                const int idx = indices[lo + base + j];
+                const float4 v = reinterpret_cast<const float4*>(V + (int64_t)idx * ld)[c];
+                *reinterpret_cast<float4*>(&Vs[j * LDV + 4 * c]) = v;
+            }
+            if (tid < nrow) {
+                const int idx = indices[lo + base + tid];
+                float wj = vals[lo + base + tid];
+                if (biasv) wj -= biasv[idx];
+                ws[tid] = wj;
+            }
+            __syncthreads();
+            for (int j = 0; j < nrow; ++j) {
+                const float wj = ws[j];
+                float va[NFB], vb[NFB];
+#pragma unroll
+                for (int i = 0; i < NFB; ++i) { va[i] = wj * Vs[j * LDV + ty + 16 * i]; vb[i] = Vs[j * LDV + tx + 16 * i]; }
+#pragma unroll
+                for (int i = 0; i < NFB; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < NFB; ++jj) acc[i][jj] += va[i] * vb[jj];
+                if (tid < FP) racc += (wj + 1.f) * Vs[j * LDV + tid];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NFB; ++i)
+#pragma unroll
+            for (int j = 0; j < NFB; ++j) {
+                const int a = ty + 16 * i, b = tx + 16 * j;
+                B[a * LDB + b] = acc[i][j] + (a == b ? 1.f : 0.f);
+            }
+        if (tid < FP) rhs[tid] = racc;
+        __syncthreads();
+
+        // ---- LU with partial pivoting on the leading f x f block (LAPACK gesv order).
+        bool singular = false;
+        for (int k = 0; k < f; ++k) {
+            // arg max |B[i][k]|, i >= k  (f <= 144 < 256: one candidate per thread)
+            float best = -1.f; int bi = k;
+            if (tid >= k && tid < f) { best = fabsf(B[tid * LDB + k]); bi = tid; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if ((tid & 63) == 0) { red[(tid >> 6) * 2] = best; red[(tid >> 6) * 2 + 1] = __int_as_float(bi); }
+            __syncthreads();
+            best = red[0]; bi = __float_as_int(red[1]);
+#pragma unroll
+            for (int wv = 1; wv < 4; ++wv) {
+                const float ob = red[wv * 2]; const int oi = __float_as_int(red[wv * 2 + 1]);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (!(best > 1e-30f)) { singular = true; break; }   // uniform: every thread reads the same red[]
+            if (bi != k) {                                      // swap rows k and bi (columns spread over threads)
+                for (int c = tid; c < f; c += 256) { const float a = B[k * LDB + c]; B[k * LDB + c] = B[bi * LDB + c]; B[bi * LDB + c] = a; }
+                if (tid == 0) { const float a = rhs[k]; rhs[k] = rhs[bi]; rhs[bi] = a; }
+            }
+            __syncthreads();
+            const float inv = 1.f / B[k * LDB + k];
+            const float rk = rhs[k];
+            // eliminate below: thread (ty, tx) covers rows k+1+ty+16a, cols k+1+tx+16b
+            for (int i = k + 1 + ty; i < f; i += 16) {
+                const float l = B[i * LDB + k] * inv;
+                for (int c = k + 1 + tx; c < f; c += 16) B[i * LDB + c] -= l * B[k * LDB + c];
+                if (tx == 0) rhs[i] -= l * rk;
+            }
+            __syncthreads();
+        }
+        if (singular) {
+            if (tid == 0) atomicAdd(fail_count, 1);
+            for (int c = tid; c < ld; c += 256) g[(int64_t)u * ld + c] = 0.f;
+            continue;
+        }
+        // ---- back substitution (column oriented)
+        for (int k = f - 1; k >= 0; --k) {
+            const float xk = rhs[k] / B[k * LDB + k];
+            __syncthreads();
+            if (tid < k) rhs[tid] -= B[tid * LDB + k] * xk;
+            if (tid == k) rhs[k] = xk;
+            __syncthreads();
+        }
+        for (int c = tid; c < ld; c += 256) g[(int64_t)u * ld + c] = (c < f) ? rhs[c] : 0.f;
+    }
+}
+
+// ----------------------------------------------------------------------------------------- spmm
+// g[u] = sum_j values[j] * V[indices[j]]  -- one wave per row, lane owns 16-byte pieces.
+__global__ __launch_bounds__(256) void spmm_kernel(const float* __restrict__ V, const int64_t* __restrict__ indptr,
+                                                   const int32_t* __restrict__ indices, const float* __restrict__ vals,
+                                                   int64_t n, int ld, float* __restrict__ g) {
+    const int lane = threadIdx.x & 63;
+    const int nch = ld >> 2;
+    for (int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); u < n; u += (int64_t)gridDim.x * 4) {
+        const int64_t lo = indptr[u], hi = indptr[u + 1];
+        for (int c = lane; c < nch; c += 64) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int64_t j = lo; j < hi; ++j) {
+                const float v = vals[j];
+                const float4 y = reinterpret_cast<const float4*>(V + (int64_t)indices[j] * ld)[c];
+                a.x += v * y.x; a.y += v * y.y; a.z += v * y.z; a.w += v * y.w;
+            }
+            reinterpret_cast<float4*>(g + u * (int64_t)ld)[c] = a;
+        }
+    }
+}
+
+int wmf_launch_spmm(const float* V, const int64_t* indptr, const int32_t* indices, const float* values, int64_t n,
+                    int ld, float* g, hipStream_t st) {
+    if (n <= 0) return 0;
+    int64_t grid = (n + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(spmm_kernel, dim3((unsigned)grid), dim3(256), 0, st, V, indptr, indices, values, n, ld, g);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- launchers
+template <int NCH>
+static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
+                       const int32_t* indices, const float* vals, int ld, float* g, hipStream_t st) {
+    const int64_t c0 = pl->count[WMF_BIN_LOW16], c1 = pl->count[WMF_BIN_LOW32];
+    if (c0 > 0)
+        hipLaunchKernelGGL((solve_low_kernel<NCH, 1>), dim3((unsigned)((c0 + 3) / 4)), dim3(256), 0, st,
+                           pl->rows[WMF_BIN_LOW16], c0, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
+                           pl->fallback_count);
+    if (c1 > 0)
+        hipLaunchKernelGGL((solve_low_kernel<NCH, 2>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
+                           pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
+                           pl->fallback_count);
+}
+
+template <int NFB>
+static void launch_general(const int32_t* rows, int64_t count, const int32_t* count_ptr, int grid, const float* V,
+                           const float* biasv, const int64_t* indptr, const int32_t* indices, const float* vals, int f,
+                           int ld, float* g, int32_t* fail_count, hipStream_t st) {
+    constexpr int FP = 16 * NFB;
+    constexpr size_t lds = ((size_t)16 * (FP + 4) + 16 + FP + 8 + (size_t)FP * (FP + 1)) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)solve_general_kernel<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((solve_general_kernel<NFB>), dim3(grid), dim3(256), lds, st, rows, count, count_ptr, V, biasv,
+                       indptr, indices, vals, f, ld, g, fail_count);
+}
+
+static int dispatch_general(const int32_t* rows, int64_t count, const int32_t* count_ptr, int grid, const float* V,
+                            const float* biasv, const int64_t* indptr, const int32_t* indices, const float* vals, int f,
+                            int ld, float* g, int32_t* fail_count, hipStream_t st) {
+    switch ((f + 15) / 16) {
+#define C(N) case N: launch_general<N>(rows, count, count_ptr, grid, V, biasv, indptr, indices, vals, f, ld, g, fail_count, st); break;
+        C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9)
+#undef C
+        default: return -1;
+    }
+    return 0;
+}
+
+int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
+                     const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fail_count,
+                     hipStream_t st) {
+    if (hipMemsetAsync(pl->fallback_count, 0, sizeof(int32_t), st) != hipSuccess) return -2;
+    switch ((ld + 15) / 16) {
+#define C(N) case N: launch_low<N>(pl, V, biasv, indptr, indices, vals, ld, g, st); break;
+        C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)
+#undef C
+        default: return -1;
+    }
+    const bool general_ok = f <= 144;
+    const int64_t heavy = pl->count[WMF_BIN_MFMA] + pl->count[WMF_BIN_GENERAL];
+    if (heavy > 0) {
+        if (!general_ok) return -1;
+        // the two heavy bins are adjacent in rows_all
+        int grid = (int)(heavy < 4096 ? heavy : 4096);
+        if (dispatch_general(pl->rows[WMF_BIN_MFMA], heavy, nullptr, grid, V, biasv, indptr, indices, vals, f, ld, g,
+                             fail_count, st)) return -1;
+    }
+    if (general_ok && pl->count[WMF_BIN_LOW16] + pl->count[WMF_BIN_LOW32] > 0) {
+        // rows bounced by the low-degree kernels (negative weights / bad pivot); count is on the device
+        if (dispatch_general(pl->fallback_rows, 0, pl->fallback_count, 256, V, biasv, indptr, indices, vals, f, ld, g,
+                             fail_count, st)) return -1;
+    }
+    return 0;
+}

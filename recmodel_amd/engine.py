@@ -1,0 +1,260 @@
+"""Device-resident WMF/ALS engine: the host side of the hot path above the C ABI.
+
+One ``AlsEngine`` per process and per GPU.  Everything numerical is a call into libwmf_hip.so
+(``include/wmf_hip.h``); torch supplies device memory, the HIP stream and -- for more than one
+GPU -- ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI).  There is no CPU code path.
+
+Restates the control structure of ``WMF.train``'s weighted branch (RecModel/wmf_model.py:134-161):
+
+    users = recompute_factors(items, C,  gamma)      -> half_step("users")
+    items = recompute_factors(users, CT, gamma)      -> half_step("items")
+    mse   = eval_prec(eval_mat)                      -> eval_sums(...)
+
+Sharding.  Rows of the side being updated are independent given the
+fixed side, so each rank owns a slice of the users and a slice of the items.  Ids are dealt
+round-robin (id i lives on rank i % W at local index i // W) so that popularity-sorted ids give
+every rank the same number of stored entries; the *position* of id i in a gathered matrix is
+(i % W) * rows_per_rank + i // W.  Per half step the only exchanges are an all-reduce of the
+f x f Gramian (fp64) and an all-gather of the freshly whitened factor block.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Csr:
+    """CSR shard resident in HBM (int64 indptr, int32 indices, fp32 values) plus its row plan."""
+
+    def __init__(self, indptr, indices, values, n_cols, f):
+        lib = _lib.load()
+        self.indptr = indptr.to(torch.int64).contiguous()
+        self.indices = indices.to(torch.int32).contiguous()
+        self.values = values.to(torch.float32).contiguous()
+        self.n_rows = self.indptr.numel() - 1
+        self.n_cols = int(n_cols)
+        self.nnz = int(self.indices.numel())
+        self.f = f
+        host_ptr = np.ascontiguousarray(self.indptr.cpu().numpy(), dtype=np.int64)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.wmf_plan_create(host_ptr.ctypes.data_as(ctypes.c_void_p), self.n_rows, f, ctypes.byref(handle)))
+        self._plan = handle
+        stats = np.zeros(4, dtype=np.int64)
+        _lib.check(lib.wmf_plan_stats(self._plan, stats.ctypes.data_as(ctypes.c_void_p)))
+        self.bin_counts = stats
+
+    def __del__(self):
+        plan, self._plan = getattr(self, "_plan", None), None
+        if plan:
+            try:
+                _lib.load().wmf_plan_destroy(plan)
+            except Exception:
+                pass
+
+
+def coo_to_csr(rows, cols, vals, n_rows):
+    """Sort COO entries by (row, col) on the device and build indptr.  Stable: duplicates survive."""
+    n_cols_bound = int(cols.max().item()) + 1 if cols.numel() else 1
+    key = rows.to(torch.int64) * n_cols_bound + cols.to(torch.int64)
+    order = torch.argsort(key, stable=True)
+    rows_s = rows[order]
+    counts = torch.bincount(rows_s, minlength=n_rows)
+    indptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=rows.device)
+    torch.cumsum(counts, 0, out=indptr[1:])
+    return indptr, cols[order].to(torch.int32), vals[order]
+
+
+class AlsEngine:
+    """Weighted-ALS state of one rank: factor blocks, whitened gathers, CSR shards."""
+
+    def __init__(self, n_users, n_items, dim, bias, gamma, device=None, group=None):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.group = group
+        if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(group)
+            self.rank = torch.distributed.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        self.n = {"users": int(n_users), "items": int(n_items)}
+        self.dim, self.bias, self.gamma = int(dim), bool(bias), float(gamma)
+        self.f = self.dim + 1 if self.bias else self.dim
+        self.ld = int(self.lib.wmf_ld_for(self.f))
+        W = self.world
+        self.rpr = {s: (self.n[s] + W - 1) // W for s in self.n}            # rows per rank (padded)
+        self.n_local = {s: len(range(self.rank, self.n[s], W)) for s in self.n}
+        dev, f32 = self.device, torch.float32
+        z = lambda *shape, dtype=f32: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
+        # local factor blocks [rows_per_rank, ld]; rows >= n_local are padding and stay zero
+        self.factors = {s: z(self.rpr[s], self.ld) for s in self.n}
+        self.g = {s: z(self.rpr[s], self.ld) for s in self.n}
+        # gathered whitened factors / bias of the fixed side [W * rows_per_rank, ld]
+        self.V = {s: z(W * self.rpr[s], self.ld) for s in self.n}
+        self.bias_vec = {s: z(W * self.rpr[s]) for s in self.n}
+        self.G = z(self.f * self.f, dtype=torch.float64)
+        self.W_white, self.W_unwhite = z(self.f, self.ld), z(self.f, self.ld)
+        self.info = z(4, dtype=torch.int32)
+        self.fail = z(4, dtype=torch.int32)
+        self.ws = torch.empty(int(self.lib.wmf_gram_workspace_bytes(self.f)), dtype=torch.uint8, device=dev)
+        self.eval_ws = torch.empty(int(self.lib.wmf_eval_workspace_bytes()), dtype=torch.uint8, device=dev)
+        self.eval_out = z(3, dtype=torch.float64)
+        self.csr = {}          # "users": shard with local user rows, "items": shard with local item rows
+        self.has_factors = {"users": False, "items": False}
+
+    # ---------------------------------------------------------------- id <-> position maps
+    def positions(self, side, ids):
+        W = self.world
+        return (ids % W) * self.rpr[side] + ids // W
+
+    def _other(self, side):
+        return "items" if side == "users" else "users"
+
+    # ---------------------------------------------------------------- data
+    def set_interactions(self, indptr, indices, values):
+        """Full user-major confidence matrix (device tensors, CSR as stored).  Builds this rank's
+        user-row shard and item-row shard (the transpose is taken here, on the device;
+        wmf_model.py:128 ``count_mat.T.tocsr()``)."""
+        dev = self.device
+        indptr = indptr.to(dev, torch.int64)
+        cols = indices.to(dev, torch.int64)
+        vals = values.to(dev, torch.float32)
+        counts = indptr[1:] - indptr[:-1]
+        rows = torch.repeat_interleave(torch.arange(self.n["users"], device=dev), counts)
+        self.csr["users"] = self._shard("users", rows, cols, vals)
+        self.csr["items"] = self._shard("items", cols, rows, vals)
+
+    def _shard(self, side, rows, cols, vals):
+        W, r = self.world, self.rank
+        other = self._other(side)
+        if W > 1:
+            mine = (rows % W) == r
+            rows, cols, vals = rows[mine], cols[mine], vals[mine]
+        local = rows // W
+        indptr, idx, v = coo_to_csr(local, self.positions(other, cols), vals, self.rpr[side])
+        return Csr(indptr, idx, v, W * self.rpr[other], self.f)
+
+    def set_factors(self, side, full):
+        """Load a full host/device [n, f] factor matrix (reference layout) into this rank's block."""
+        full = torch.as_tensor(full, dtype=torch.float32)
+        mine = full[self.rank::self.world].to(self.device)
+        blk = self.factors[side]
+        blk.zero_()
+        blk[: mine.shape[0], : self.f] = mine
+        self.has_factors[side] = True
+
+    def get_factors(self, side):
+        """Full [n, f] factor matrix on the host (gathers the blocks of all ranks)."""
+        blk = self.factors[side]
+        if self.world > 1:
+            full = torch.empty(self.world * self.rpr[side], self.ld, dtype=torch.float32, device=self.device)
+            torch.distributed.all_gather_into_tensor(full, blk, group=self.group)
+        else:
+            full = blk
+        ids = torch.arange(self.n[side], device=self.device)
+        return full[self.positions(side, ids)][:, : self.f].cpu().numpy()
+
+    # ---------------------------------------------------------------- one half step
+    def prepare(self, fixed):
+        """Gramian of the fixed side, its Cholesky factor, and the gathered whitened factors.
+        wmf_model.py:215 / :328-332."""
+        lib, st = self.lib, _stream()
+        blk = self.factors[fixed]
+        _lib.check(lib.wmf_gram(_ptr(blk), self.n_local[fixed], self.f, self.ld, int(self.bias), _ptr(self.G),
+                                _ptr(self.ws), st))
+        if self.world > 1:
+            torch.distributed.all_reduce(self.G, group=self.group)
+        _lib.check(lib.wmf_factorize(_ptr(self.G), self.f, self.ld, self.gamma, _ptr(self.W_white),
+                                     _ptr(self.W_unwhite), _ptr(self.info), _ptr(self.ws), st))
+        V, bvec = self.V[fixed], self.bias_vec[fixed]
+        lo = self.rank * self.rpr[fixed]
+        v_loc = V[lo: lo + self.rpr[fixed]]
+        b_loc = bvec[lo: lo + self.rpr[fixed]]
+        _lib.check(lib.wmf_row_transform(_ptr(blk), self.n_local[fixed], self.f, self.ld, _ptr(self.W_white),
+                                         int(self.bias), _ptr(v_loc), _ptr(b_loc) if self.bias else None, st))
+        if self.world > 1:
+            torch.distributed.all_gather_into_tensor(V, v_loc, group=self.group)
+            if self.bias:
+                torch.distributed.all_gather_into_tensor(bvec, b_loc, group=self.group)
+
+    def update(self, side):
+        """Solve every local row of ``side`` against the prepared fixed side.  wmf_model.py:220-239."""
+        lib, st = self.lib, _stream()
+        fixed = self._other(side)
+        c = self.csr[side]
+        _lib.check(lib.wmf_solve_rows(c._plan, _ptr(self.V[fixed]), _ptr(self.bias_vec[fixed]) if self.bias else None,
+                                      _ptr(c.indptr), _ptr(c.indices), _ptr(c.values), c.n_rows, self.f, self.ld,
+                                      _ptr(self.g[side]), _ptr(self.fail), st))
+        _lib.check(lib.wmf_row_transform(_ptr(self.g[side]), self.n_local[side], self.f, self.ld,
+                                         _ptr(self.W_unwhite), 0, _ptr(self.factors[side]), None, st))
+        self.has_factors[side] = True
+
+    def half_step(self, side):
+        """``side`` <- recompute_factors(other side, C or C^T, gamma)."""
+        self.prepare(self._other(side))
+        self.update(side)
+
+    def half_step_unweighted(self, side):
+        """Closed form of the un-weighted branch, wmf_model.py:85,88:
+        side = R . Y . (Y^T Y + gamma I)^-1  =  (R . V) . L^-1  with V = Y L^-T."""
+        lib, st = self.lib, _stream()
+        fixed = self._other(side)
+        self.prepare(fixed)
+        c = self.csr[side]
+        _lib.check(lib.wmf_spmm_rows(_ptr(self.V[fixed]), _ptr(c.indptr), _ptr(c.indices), _ptr(c.values), c.n_rows,
+                                     self.f, self.ld, _ptr(self.g[side]), st))
+        _lib.check(lib.wmf_row_transform(_ptr(self.g[side]), self.n_local[side], self.f, self.ld,
+                                         _ptr(self.W_unwhite), 0, _ptr(self.factors[side]), None, st))
+        self.has_factors[side] = True
+
+    def check_numerics(self):
+        """Host sync: raise if a Gramian was not positive definite or a row system was singular."""
+        info, fail = int(self.info[0].item()), int(self.fail[0].item())
+        if info:
+            raise _lib.WmfNumericError(f"Gramian + gamma*I is not positive definite (leading minor {info})")
+        if fail:
+            self.fail.zero_()
+            raise _lib.WmfNumericError(f"{fail} row systems were singular")
+
+    # ---------------------------------------------------------------- evaluation
+    def make_eval_shard(self, indptr, indices, values):
+        """User-row shard of a utility matrix for eval_sums (columns are item positions)."""
+        dev = self.device
+        indptr = indptr.to(dev, torch.int64)
+        counts = indptr[1:] - indptr[:-1]
+        rows = torch.repeat_interleave(torch.arange(self.n["users"], device=dev), counts)
+        return self._shard("users", rows, indices.to(dev, torch.int64), values.to(dev, torch.float32))
+
+    def eval_sums(self, shard):
+        """(sum of squared errors, sum of absolute errors, count) over the stored non-zero entries
+        of ``shard``; all-reduced over ranks.  base_model.py:163-176."""
+        lib, st = self.lib, _stream()
+        items = self.factors["items"]
+        if self.world > 1:
+            full = torch.empty(self.world * self.rpr["items"], self.ld, dtype=torch.float32, device=self.device)
+            torch.distributed.all_gather_into_tensor(full, items, group=self.group)
+            items = full
+        _lib.check(lib.wmf_eval_sqerr(_ptr(self.factors["users"]), _ptr(items), self.f, self.ld, int(self.bias),
+                                      _ptr(shard.indptr), _ptr(shard.indices), _ptr(shard.values), shard.n_rows,
+                                      _ptr(self.eval_out), _ptr(self.eval_ws), st))
+        if self.world > 1:
+            torch.distributed.all_reduce(self.eval_out, group=self.group)
+        return tuple(float(x) for x in self.eval_out.cpu())
+
+    # ---------------------------------------------------------------- roofline bookkeeping
+    def algorithmic_bytes_half(self, side):
+        """z*(4f+8) + n*(4f+4) + 4f^2 for this rank's rows, plus 4*m*f for
+        the Gramian of the fixed side (this rank's share of it)."""
+        c = self.csr[side]
+        f = self.f
+        return c.nnz * (4 * f + 8) + self.n_local[side] * (4 * f + 4) + 4 * f * f + 4 * self.n_local[self._other(side)] * f

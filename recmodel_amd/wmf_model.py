@@ -1,0 +1,265 @@
+"""``WMF``: weighted matrix factorisation by alternating least squares, on MI355X.
+
+Same class surface as RecModel/wmf_model.py:8-351 -- constructor, ``train`` / ``predict`` /
+``rank``, ``recompute_factors[_bias]``, public ``users`` / ``items`` host arrays -- with the
+numerical work done by libwmf_hip.so through ``AlsEngine``.  ``cores`` is accepted for
+compatibility (it selected a multiprocessing pool in the reference) and ignored beyond the
+reference's argument check.  There is no CPU fallback.
+"""
+import ctypes
+import time
+
+import numpy as np
+import scipy.sparse
+import torch
+
+from . import _lib
+from .base_model import RecModel
+from .engine import AlsEngine, _ptr, _stream
+
+
+def _csr_parts(mat):
+    mat = scipy.sparse.csr_matrix(mat) if not scipy.sparse.isspmatrix_csr(mat) else mat
+    return (torch.from_numpy(mat.indptr.astype(np.int64)), torch.from_numpy(mat.indices.astype(np.int64)),
+            torch.from_numpy(mat.data.astype(np.float32)))
+
+
+class WMF(RecModel):
+
+    def __init__(self, num_items, num_users, dim, gamma, weighted=None, bias=False, seed=1993, dtype='float32'):
+        # wmf_model.py:10-23 -- the reference seeds the global legacy RNG and draws float64 uniforms
+        np.random.seed(seed)
+        self.bias = bias
+        self.gamma = gamma
+        if self.bias is False:
+            self.items = np.random.random((num_items, dim)).astype(dtype=dtype)
+        elif self.bias is True:
+            self.items = np.random.random((num_items, (dim + 1))).astype(dtype=dtype)
+        self.users = None
+        self.num_users = num_users
+        self.num_items = num_items
+        self.dim = dim
+        self.weighted = weighted
+        self.dtype = dtype
+        self._engine = None
+        self._dev = None           # (id(users), id(items), users_t, items_t) cache for predict()
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _new_engine(self):
+        return AlsEngine(self.num_users, self.num_items, self.dim, self.bias is True, self.gamma)
+
+    def _device_factors(self):
+        """Device copies of the public host arrays (re-uploaded when the user swapped them)."""
+        _lib.require_gpu()
+        key = (id(self.users), id(self.items))
+        if self._dev is None or self._dev[0] != key:
+            lib = _lib.load()
+            f = self.items.shape[1]
+            ld = int(lib.wmf_ld_for(f))
+
+            def up(a):
+                t = torch.zeros(a.shape[0], ld, dtype=torch.float32, device="cuda")
+                t[:, :f] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+                return t
+            self._dev = (key, up(self.users), up(self.items), f, ld)
+        return self._dev[1:]
+
+    # ------------------------------------------------------------------ a7: predict
+    def predict(self, users, items):
+        """Scores for (user, item) pairs; one user or one item broadcasts.  wmf_model.py:191-211."""
+        if (type(users) == list or type(users) == np.ndarray) and (type(items) == list or type(items) == np.ndarray):
+            if len(users) != len(items):
+                if not (len(users) == 1 or len(items) == 0):
+                    raise ValueError("users and items need to have the same length or only one user / item needs to be provided.")
+        u = np.atleast_1d(np.asarray(users)).astype(np.int32)
+        i = np.atleast_1d(np.asarray(items)).astype(np.int32)
+        if len(u) == 0 or len(i) == 0:
+            return np.zeros(0, dtype=self.items.dtype)
+        if len(u) != len(i) and len(i) == 1:
+            i = np.repeat(i, len(u))
+        if (u.min() < -self.users.shape[0] or u.max() >= self.users.shape[0]
+                or i.min() < -self.items.shape[0] or i.max() >= self.items.shape[0]):
+            raise IndexError("user or item index out of bounds")
+        u = np.where(u < 0, u + self.users.shape[0], u).astype(np.int32)
+        i = np.where(i < 0, i + self.items.shape[0], i).astype(np.int32)
+        users_t, items_t, f, ld = self._device_factors()
+        lib = _lib.load()
+        ut, it = torch.from_numpy(u).cuda(), torch.from_numpy(i).cuda()
+        out = torch.empty(max(len(u), len(i)), dtype=torch.float32, device="cuda")
+        _lib.check(lib.wmf_predict_pairs(_ptr(users_t), _ptr(items_t), f, ld, int(self.bias is True), _ptr(ut), len(u),
+                                         _ptr(it), len(i), _ptr(out), _stream()))
+        return out.cpu().numpy().astype(self.users.dtype, copy=False)
+
+    # ------------------------------------------------------------------ a10: rank
+    def rank(self, items, users, topn=None):
+        """Top-n of the candidate ``items`` for a user, best first.  wmf_model.py:25-47."""
+        if topn is None:
+            topn = len(items)
+        if isinstance(users, list):
+            return [self.rank(items, user, topn) for user in users]
+        if not type(items) == np.ndarray:
+            items = np.array(items)
+        scores = self.predict(users=users, items=items)
+        if len(scores) * 0.5 > topn:
+            return items[np.argpartition(scores, list(range(-topn, 0, 1)))[-topn:]][::-1]
+        return items[np.argsort(scores)[-topn:]][::-1]
+
+    # ------------------------------------------------------------------ a8: eval_prec backend
+    def _eval_sums(self, utility_mat):
+        eng = self._engine
+        if eng is None or not (eng.has_factors["users"] and eng.has_factors["items"]) or self._stale():
+            eng = self._new_engine()
+            eng.set_factors("users", self.users)
+            eng.set_factors("items", self.items)
+        shard = eng.make_eval_shard(*_csr_parts(utility_mat))
+        return eng.eval_sums(shard)
+
+    def _stale(self):
+        return getattr(self, "_synced", None) != (id(self.users), id(self.items))
+
+    def _pull(self, eng, sides=("users", "items")):
+        for s in sides:
+            setattr(self, s, eng.get_factors(s).astype(self.dtype, copy=False))
+        self._synced = (id(self.users), id(self.items))
+        self._dev = None
+
+    # ------------------------------------------------------------------ a3 / a4: operator seam
+    def recompute_factors(self, Y, C, lambda_reg):
+        """X_new for fixed factors Y and CSR C.  wmf_model.py:213-240 (host buffers in, host out)."""
+        return self._recompute(Y, C, lambda_reg, 0)
+
+    def recompute_factors_bias(self, Y, C, lambda_reg, cores=1):
+        """Bias variant: column 0 of Y is the fixed side's bias.  wmf_model.py:311-351."""
+        return self._recompute(Y, C, lambda_reg, 1)
+
+    def _recompute(self, Y, C, lambda_reg, bias):
+        _lib.require_gpu()
+        lib = _lib.load()
+        Y = np.ascontiguousarray(Y, dtype=np.float32)
+        C = scipy.sparse.csr_matrix(C)
+        indptr = np.ascontiguousarray(C.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(C.indices, dtype=np.int32)
+        values = np.ascontiguousarray(C.data, dtype=np.float32)
+        X = np.empty((C.shape[0], Y.shape[1]), dtype=np.float32)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        _lib.check(lib.wmf_recompute_factors_host(vp(Y), Y.shape[0], Y.shape[1], bias, vp(indptr), vp(indices),
+                                                  vp(values), C.shape[0], float(lambda_reg), vp(X)))
+        return X.astype(self.dtype, copy=False)
+
+    # ------------------------------------------------------------------ a2: train
+    def train(self, utility_mat, iterations, verbose=0, eval_mat=None, count_mat=None, alpha=10,
+              cores=4, stopping_rounds=3, dtype='float64', min_improvement=0.0001,
+              pre_process_count='log', beta=1, preprocess_mat=False):
+        """Alternating least squares with early stopping on eval MSE.  wmf_model.py:49-189.
+        Returns the index of the last iteration run."""
+        utility_mat = utility_mat.copy()
+        if count_mat is not None:
+            count_mat = count_mat.copy()
+        if self.bias is True and self.weighted is False:
+            print("Bias computation is only implemented for weighted matrix factorization.")
+        if eval_mat is None and verbose > 1:
+            print("Since no explicit evaluation was provided the train matrix is used for evaluation.")
+            eval_mat = utility_mat
+        if preprocess_mat == True:  # noqa: E712  (the reference compares with ==)
+            if pre_process_count == 'log':
+                utility_mat.data = alpha * np.log(1 + beta * utility_mat.data)
+            elif pre_process_count == 'linear':
+                utility_mat.data = alpha * utility_mat.data
+
+        eng = self._engine = self._new_engine()
+        eng.set_factors("items", self.items)
+        last_mse = - np.inf
+        count_improvement = 0
+
+        if self.weighted is not True:
+            # closed-form un-weighted branch, wmf_model.py:73-115
+            if self.bias is True:
+                raise ValueError("operands could not be broadcast together: the un-weighted branch has no bias column")
+            eng.set_interactions(*_csr_parts(utility_mat))
+            eval_shard = self._train_eval_shard(eng, eval_mat)
+            train_shard = eng.make_eval_shard(*_csr_parts(utility_mat)) if verbose > 1 else None
+            for iter in range(iterations):
+                if verbose > 0:
+                    print(f"Starting fitting iteration {iter}")
+                eng.half_step_unweighted("users")
+                eng.half_step_unweighted("items")
+                eng.check_numerics()
+                mse_eval = self._mse(eng, eval_shard)
+                if verbose > 0:
+                    print(f"Current eval mse is {mse_eval}")
+                if verbose > 1:
+                    print(f"\tMSE Eval: {mse_eval}")
+                    print(f"\tMSE Train: {self._mse(eng, train_shard)}")
+                if mse_eval * (1 + min_improvement) > last_mse:
+                    count_improvement += 1
+                else:
+                    count_improvement = 0
+                last_mse = mse_eval
+                if count_improvement >= stopping_rounds:
+                    break
+            self._pull(eng)
+            self.users, self.items = self.users.astype(np.float64), self.items.astype(np.float64)
+            self._synced = (id(self.users), id(self.items))
+            if verbose > 0:
+                print("Training was completed.")
+            if verbose > 1:
+                print(f"MSE Eval at iteration {iter}: {self._mse(eng, eval_shard)}")
+                print(f"MSE Train at iteration {iter}: {self._mse(eng, train_shard)}")
+            return iter
+
+        # weighted branch, wmf_model.py:116-189
+        if pre_process_count not in ('log', 'linear'):
+            raise ValueError(f"Pre_process_count {pre_process_count} is not implement please use log or linear.")
+        if not cores >= 1:
+            raise ValueError(f"Values of cores has to be positive not {cores}")
+        if self.bias is not True and self.bias is not False:
+            raise ValueError(f"self.bias = {self.bias} is unknown. Only True / False are allowed.")
+        indptr, indices, values = _csr_parts(count_mat)
+        values = values.cuda()
+        _lib.check(eng.lib.wmf_confidence_transform(_ptr(values), values.numel(), float(alpha), float(beta),
+                                                    0 if pre_process_count == 'log' else 1, _stream()))
+        eng.set_interactions(indptr, indices, values)      # also builds the item-major shard (:128)
+        eval_shard = self._train_eval_shard(eng, eval_mat)
+        train_shard = eng.make_eval_shard(*_csr_parts(utility_mat)) if verbose > 1 else None
+
+        for iter in range(iterations):
+            if verbose > 0:
+                print(f"Starting fitting iteration {iter}")
+            start = time.time()
+            eng.half_step("users")
+            eng.half_step("items")
+            eng.check_numerics()
+            if self.bias is True and cores == 1:
+                print(f"Iteration {iter} took {round(time.time() - start, 4)} seconds.")
+            mse_eval = self._mse(eng, eval_shard)
+            if mse_eval * (1 + min_improvement) > last_mse:
+                count_improvement += 1
+            else:
+                count_improvement = 0
+            last_mse = mse_eval
+            if verbose > 0:
+                print(f"Current eval mse is {mse_eval}")
+            if verbose > 1:
+                print(f"\tMSE Eval: {mse_eval}")
+                print(f"\tMSE Train: {self._mse(eng, train_shard)}")
+            if count_improvement >= stopping_rounds:
+                break
+        self._pull(eng)
+        if verbose > 0:
+            print("Training was completed.")
+        if verbose > 1:
+            print(f"MSE Eval at iteration {iter}: {self._mse(eng, eval_shard)}")
+            print(f"MSE Train at iteration {iter}: {self._mse(eng, train_shard)}")
+        return iter
+
+    @staticmethod
+    def _train_eval_shard(eng, eval_mat):
+        if eval_mat is None:
+            # the reference fails inside eval_prec here (wmf_model.py:61-63 only substitutes when verbose > 1)
+            raise AttributeError("'NoneType' object has no attribute 'nonzero'")
+        return eng.make_eval_shard(*_csr_parts(eval_mat))
+
+    @staticmethod
+    def _mse(eng, shard):
+        sq, _, cnt = eng.eval_sums(shard)
+        return sq / cnt if cnt else float('nan')

@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory by running the *reference* WMF class.
+
+Run in the build container only (the reference lives at /root/reference and never travels):
+
+    python3 -B tests/golden/make_golden.py
+
+The reference package cannot be imported whole (its ``__init__`` needs compiled Cython
+modules), so the two files on the WMF path are loaded in isolation:
+an empty ``RecModel`` package object bypasses ``__init__``, an empty ``sharedmem`` module
+satisfies the unused import at base_model.py:8, and the MKL runtime that ``MKLThreads``
+dlopens (base_model.py:191) is pointed at /opt/conda/lib.  Nothing of the reference is
+copied: the outputs are data (inputs + expected outputs) saved as ``.npz``.
+"""
+import ctypes
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import scipy.sparse as sp
+
+sys.dont_write_bytecode = True
+REF = "/root/reference/RecModel"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_reference():
+    sys.modules.setdefault("sharedmem", types.ModuleType("sharedmem"))
+    pkg = types.ModuleType("RecModel")
+    pkg.__path__ = [REF]
+    sys.modules["RecModel"] = pkg
+    mods = {}
+    for name in ("base_model", "wmf_model"):
+        spec = importlib.util.spec_from_file_location(f"RecModel.{name}", f"{REF}/{name}.py")
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f"RecModel.{name}"] = mod
+        spec.loader.exec_module(mod)
+        mods[name] = mod
+    mods["base_model"].MKLThreads._mkl_rt = ctypes.CDLL("/opt/conda/lib/libmkl_rt.so")
+    return mods["wmf_model"].WMF
+
+
+def make_counts(n_users, n_items, mean_deg, seed, dtype):
+    """Small ragged count matrix with the edge cases SURVEY.md section 8c asks for:
+    an empty row, an empty column, a stored zero, one very heavy row and one heavy column."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    deg = np.maximum(rng.poisson(mean_deg, n_users), 1)
+    deg[3] = 0                       # empty user row
+    deg[7] = n_items - 5             # very heavy row
+    pop = 1.0 / np.arange(1, n_items + 1) ** 0.6
+    pop[11] = 0.0                    # item never chosen -> empty row of the transpose
+    pop /= pop.sum()
+    rows, cols = [], []
+    for u in range(n_users):
+        c = np.sort(rng.choice(n_items, size=min(deg[u], n_items - 1), replace=False, p=pop))
+        rows.append(np.full(len(c), u))
+        cols.append(c)
+    rows = np.concatenate(rows)
+    cols = np.concatenate(cols)
+    vals = (1 + rng.geometric(0.5, len(rows))).astype(dtype)
+    vals[5] = 0                      # a *stored* zero: still contributes (w+1)*y to b
+    m = sp.csr_matrix((vals, (rows, cols)), shape=(n_users, n_items), dtype=dtype)
+    assert m.nnz == len(vals), "stored zero must stay stored"
+    return m
+
+
+def csr_fields(prefix, m):
+    return {f"{prefix}_indptr": m.indptr.copy(), f"{prefix}_indices": m.indices.copy(),
+            f"{prefix}_data": m.data.copy(), f"{prefix}_shape": np.array(m.shape)}
+
+
+def main():
+    WMF = load_reference()
+    n_users, n_items = 300, 120
+
+    # ---- a1: initial item factors ------------------------------------------------
+    init = {}
+    for bias in (False, True):
+        mdl = WMF(num_items=37, num_users=5, dim=6, gamma=0.1, weighted=True, bias=bias, seed=1993)
+        init[f"items_bias{int(bias)}"] = mdl.items.copy()
+    mdl = WMF(num_items=9, num_users=5, dim=4, gamma=0.1, weighted=True, seed=7)
+    init["items_seed7"] = mdl.items.copy()
+    np.savez_compressed(f"{OUT}/init.npz", **init)
+
+    # ---- a3/a4: half steps from the fixed init, bias x count dtype ---------------
+    for bias in (False, True):
+        for cdt in ("float32", "float64"):
+            counts = make_counts(n_users, n_items, 6, seed=11, dtype=cdt)
+            mdl = WMF(num_items=n_items, num_users=n_users, dim=16, gamma=0.1, weighted=True,
+                      bias=bias, seed=1993)
+            C = counts.copy()
+            C.data = 10 * np.log(1 + C.data)          # the train() defaults, wmf_model.py:120
+            CT = C.T.tocsr()
+            items0 = mdl.items.copy()
+            if bias:
+                users1 = mdl.recompute_factors_bias(items0.copy(), C.copy(), 0.1, cores=1)
+                items1 = mdl.recompute_factors_bias(users1.copy(), CT.copy(), 0.1, cores=1)
+                users2 = mdl.recompute_factors_bias(items1.copy(), C.copy(), 0.1, cores=1)
+            else:
+                users1 = mdl.recompute_factors(items0, C, 0.1)
+                items1 = mdl.recompute_factors(users1, CT, 0.1)
+                users2 = mdl.recompute_factors(items1, C, 0.1)
+            out = dict(items0=items0, users1=users1, items1=items1, users2=users2, gamma=0.1)
+            out.update(csr_fields("C", C))
+            out.update(csr_fields("CT", CT))
+            out.update(csr_fields("counts", counts))
+            np.savez_compressed(f"{OUT}/half_bias{int(bias)}_{cdt}.npz", **out)
+
+    # ---- a5/a6: the Pool variants return float64 -----------------
+    counts = make_counts(40, 30, 4, seed=5, dtype="float64")
+    C = counts.copy()
+    C.data = 10 * np.log(1 + C.data)
+    out = {}
+    for bias in (False, True):
+        mdl = WMF(num_items=30, num_users=40, dim=8, gamma=0.1, weighted=True, bias=bias, seed=1993)
+        if bias:
+            u = mdl.recompute_factors_bias_par(mdl.items.copy(), C.copy(), 0.1, cores=2)
+        else:
+            u = mdl.recompute_factors_par(mdl.items, C, 0.1, cores=2)
+        out[f"users_par_bias{int(bias)}"] = u
+        out[f"items0_bias{int(bias)}"] = mdl.items.copy()
+    out.update(csr_fields("C", C))
+    np.savez_compressed(f"{OUT}/half_par.npz", **out)
+
+    # ---- a2/a7/a8/a10: full train() control flow, predict, eval_prec, rank -------
+    for tag, bias, iters, rounds, min_imp in (("run", False, 4, 3, 1e-4), ("stop", False, 8, 2, 0.5),
+                                              ("bias", True, 3, 3, 1e-4)):
+        counts = make_counts(n_users, n_items, 6, seed=23, dtype="float64")
+        util = counts.copy()
+        util.data = np.minimum(util.data, 5.0)
+        mdl = WMF(num_items=n_items, num_users=n_users, dim=12, gamma=0.1, weighted=True, bias=bias,
+                  seed=1993)
+        history = []
+        inner = mdl.eval_prec
+
+        def recorder(mat, metric="mse", _inner=inner, _h=history):
+            v = _inner(mat, metric)
+            _h.append(v)
+            return v
+        mdl.eval_prec = recorder
+        devnull = open(os.devnull, "w")
+        stdout, sys.stdout = sys.stdout, devnull      # bias+cores==1 prints per iteration (:153)
+        try:
+            last = mdl.train(utility_mat=util, iterations=iters, verbose=0, eval_mat=util,
+                             count_mat=counts, cores=1, stopping_rounds=rounds, min_improvement=min_imp)
+        finally:
+            sys.stdout = stdout
+        del mdl.eval_prec
+        pu = np.array([0, 1, 2, 7, 50, 299, 3])
+        pi = np.array([0, 5, 11, 119, 60, 1, 2])
+        cand = np.arange(0, n_items, 2)
+        out = dict(last_iter=last, mse=np.array(history), users=mdl.users, items=mdl.items,
+                   pred_users=pu, pred_items=pi, pred=mdl.predict(pu, pi),
+                   pred_one_user=mdl.predict(np.array([7]), cand),
+                   rank_cand=cand, rank_top5=mdl.rank(cand, 7, topn=5),
+                   rank_top40=mdl.rank(cand, 7, topn=40), rank_all=mdl.rank(cand, 7),
+                   rank_list0=np.array(mdl.rank(cand, [1, 2], topn=3)),
+                   mse_final=mdl.eval_prec(util), rmse_final=mdl.eval_prec(util, "rmse"),
+                   mae_final=mdl.eval_prec(util, "mae"),
+                   iterations=iters, stopping_rounds=rounds, min_improvement=min_imp, dim=12)
+        out.update(csr_fields("counts", counts))
+        out.update(csr_fields("util", util))
+        np.savez_compressed(f"{OUT}/train_{tag}.npz", **out)
+
+    # ---- un-weighted branch (weighted=None is the constructor default) -----------
+    counts = make_counts(n_users, n_items, 6, seed=31, dtype="float64")
+    util = counts.copy()
+    util.data = np.minimum(util.data, 5.0)
+    mdl = WMF(num_items=n_items, num_users=n_users, dim=10, gamma=0.5, seed=1993)
+    last = mdl.train(utility_mat=util, iterations=2, eval_mat=util, stopping_rounds=5)
+    out = dict(last_iter=last, users=mdl.users, items=mdl.items, mse_final=mdl.eval_prec(util))
+    out.update(csr_fields("util", util))
+    np.savez_compressed(f"{OUT}/train_unweighted.npz", **out)
+
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(f"{OUT}/{f}"))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""The oracle (oracle/wmf_oracle.py) against golden vectors captured from the reference WMF class
+(tests/golden/make_golden.py).  CPU only.  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from conftest import csr_from, load_golden
+from oracle import wmf_oracle as orc
+
+# The oracle repeats the reference's NumPy calls, so on the same BLAS it agrees to the last bit;
+# the tolerance only leaves room for a different BLAS/LAPACK build on the GPU box.
+RTOL, ATOL = 2e-5, 2e-6
+
+
+def test_init_items_matches_reference_rng():
+    g = load_golden("init.npz")
+    np.testing.assert_array_equal(orc.init_items(37, 6, False, 1993), g["items_bias0"])
+    np.testing.assert_array_equal(orc.init_items(37, 6, True, 1993), g["items_bias1"])
+    np.testing.assert_array_equal(orc.init_items(9, 4, False, 7), g["items_seed7"])
+    assert g["items_bias1"].shape == (37, 7) and g["items_bias0"].dtype == np.float32
+
+
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("cdt", ["float32", "float64"])
+def test_half_steps(bias, cdt):
+    g = load_golden(f"half_bias{int(bias)}_{cdt}.npz")
+    C, CT = csr_from(g, "C"), csr_from(g, "CT")
+    assert C.data.dtype == np.dtype(cdt)
+    step = orc.recompute_factors_bias if bias else orc.recompute_factors
+    users1 = step(g["items0"], C, float(g["gamma"]))
+    np.testing.assert_allclose(users1, g["users1"], rtol=RTOL, atol=ATOL)
+    assert users1.dtype == np.float32
+    items1 = step(g["users1"], CT, float(g["gamma"]))
+    np.testing.assert_allclose(items1, g["items1"], rtol=RTOL, atol=ATOL)
+    users2 = step(g["items1"], C, float(g["gamma"]))
+    np.testing.assert_allclose(users2, g["users2"], rtol=RTOL, atol=ATOL)
+    # edge cases baked into the fixture: empty user row -> zeros; never-chosen item -> zeros
+    assert np.all(g["users1"][3] == 0) and np.all(users1[3] == 0)
+    assert np.all(g["items1"][11] == 0) and np.all(items1[11] == 0)
+    # confidence transform of the raw counts gives C (train() defaults)
+    counts = csr_from(g, "counts")
+    np.testing.assert_allclose(orc.confidence_transform(counts.data), C.data, rtol=1e-6)
+
+
+def test_pool_variants_are_float64_and_equal_serial():
+    g = load_golden("half_par.npz")
+    C = csr_from(g, "C")
+    for bias in (False, True):
+        ref = g[f"users_par_bias{int(bias)}"]
+        assert ref.dtype == np.float64
+        step = orc.recompute_factors_bias if bias else orc.recompute_factors
+        got = step(g[f"items0_bias{int(bias)}"], C, 0.1, out_dtype="float64")
+        np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag,bias", [("run", False), ("stop", False), ("bias", True)])
+def test_train_control_flow_predict_rank(tag, bias):
+    g = load_golden(f"train_{tag}.npz")
+    counts, util = csr_from(g, "counts"), csr_from(g, "util")
+    last, hist, users, items = orc.train(
+        num_items=util.shape[1], num_users=util.shape[0], dim=int(g["dim"]), gamma=0.1,
+        utility_mat=util, iterations=int(g["iterations"]), eval_mat=util, count_mat=counts,
+        weighted=True, bias=bias, stopping_rounds=int(g["stopping_rounds"]),
+        min_improvement=float(g["min_improvement"]))
+    assert last == int(g["last_iter"])
+    if tag == "stop":
+        assert last < int(g["iterations"]) - 1          # the fixture does stop early
+    np.testing.assert_allclose(hist, g["mse"], rtol=1e-5)
+    np.testing.assert_allclose(users, g["users"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(items, g["items"], rtol=1e-4, atol=1e-5)
+    # a7 / a8 / a10 on the reference's own final factors
+    U, I = g["users"], g["items"]
+    np.testing.assert_allclose(orc.predict(U, I, g["pred_users"], g["pred_items"], bias), g["pred"], rtol=1e-6)
+    np.testing.assert_allclose(orc.predict(U, I, np.array([7]), g["rank_cand"], bias), g["pred_one_user"], rtol=1e-6)
+    np.testing.assert_allclose(orc.eval_prec(U, I, util, bias), g["mse_final"], rtol=1e-6)
+    np.testing.assert_allclose(orc.eval_prec(U, I, util, bias, "rmse"), g["rmse_final"], rtol=1e-6)
+    np.testing.assert_allclose(orc.eval_prec(U, I, util, bias, "mae"), g["mae_final"], rtol=1e-6)
+    cand = g["rank_cand"]
+    np.testing.assert_array_equal(orc.rank(U, I, cand, 7, 5, bias), g["rank_top5"])      # argpartition side
+    np.testing.assert_array_equal(orc.rank(U, I, cand, 7, 40, bias), g["rank_top40"])    # argsort side
+    np.testing.assert_array_equal(orc.rank(U, I, cand, 7, None, bias), g["rank_all"])
+    np.testing.assert_array_equal(np.array([orc.rank(U, I, cand, u, 3, bias) for u in (1, 2)]), g["rank_list0"])
+
+
+def test_predict_length_mismatch_raises():
+    U = np.ones((4, 3), np.float32)
+    with pytest.raises(ValueError):
+        orc.predict(U, U, np.array([0, 1]), np.array([0, 1, 2]))
+
+
+def test_unweighted_branch():
+    g = load_golden("train_unweighted.npz")
+    util = csr_from(g, "util")
+    last, hist, users, items = orc.train(
+        num_items=util.shape[1], num_users=util.shape[0], dim=10, gamma=0.5, utility_mat=util,
+        iterations=2, eval_mat=util, weighted=None, stopping_rounds=5)
+    assert last == int(g["last_iter"]) and users.dtype == np.float64
+    np.testing.assert_allclose(users, g["users"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(items, g["items"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(hist[-1], g["mse_final"], rtol=1e-9)
+
+
+def test_bad_confidence_mode_raises():
+    with pytest.raises(ValueError):
+        orc.confidence_transform(np.ones(3), mode="sqrt")
