@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""WMF/ALS throughput on MI355X: one "step" = one ALS iteration (users half step + items half
+step, each with its Gramian, factorisation, whitening, row solve and -- on more than one GPU --
+the Gramian all-reduce and the all-gather of the whitened block) over a synthetic confidence
+matrix that is already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|tiny] [--zipf A]
+
+For N > 1 the driver launches one rank per GPU through torch.distributed.run; ranks talk RCCL.
+Scaling is weak: each GPU brings its own ``n_users`` users (the item catalogue is shared), so the
+stored entries per GPU stay fixed.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from recmodel_amd import _lib, synth  # noqa: E402
+from recmodel_amd.engine import AlsEngine  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+F32_MFMA_PEAK_TF = 157.3  # dense f32-input MFMA peak
+SOLVE_BINS = {4: 0, 5: 1, 11: 2, 6: 3}   # profile slot -> plan bin whose rows that kernel processes
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg2", choices=sorted(synth.CONFIGS))
+    ap.add_argument("--zipf", type=float, default=0.0, help="item popularity exponent (0 = uniform)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-users", type=int, default=0, help="user rows in the CPU-baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg_name, counts_csr, k, bias, gamma, n_items, sample_users):
+    """The oracle's NumPy restatement of recompute_factors[_bias] (same per-row gather / dot / solve
+    structure as RecModel/wmf_model.py:220-239, one thread) on a row sample of the same matrix."""
+    from oracle import wmf_oracle as orc
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=1):
+        C = counts_csr[:sample_users].astype(np.float64)
+        C.data = orc.confidence_transform(C.data)
+        items = orc.init_items(n_items, k, bias)
+        step = orc.recompute_factors_bias if bias else orc.recompute_factors
+        t0 = time.perf_counter()
+        users = step(items, C, gamma)
+        t_u = time.perf_counter() - t0
+        # item half on the same user sample, with a 1:10 share of item rows as in the full job
+        CT = C.T.tocsr()
+        sample_items = max(1, sample_users // 10)
+        CT = CT[:sample_items]
+        t0 = time.perf_counter()
+        step(users, CT, gamma)
+        t_i = time.perf_counter() - t0
+    rows = sample_users + sample_items
+    return {"value": rows / (t_u + t_i), "unit": "row-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{cfg_name}: first {sample_users} user rows ({C.nnz} nnz, {t_u:.1f}s) + first {sample_items} "
+                      f"item rows of their transpose ({CT.nnz} nnz, {t_i:.1f}s), NumPy per-row loop, 1 BLAS thread",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    dev = torch.device(f"cuda:{local_rank}")
+    lib = _lib.load()
+
+    n_users_1, n_items, dbar, k, bias = synth.CONFIGS[args.config]
+    n_users = n_users_1 * world                     # weak scaling over users
+    gamma = 0.1
+    seed = 1993 + {"cfg1": 1, "cfg2": 2, "cfg3": 3, "tiny": 9}[args.config]
+
+    # ---- synthetic workload, generated on the GPU (identical on every rank) -----------------
+    t0 = time.perf_counter()
+    parts = [synth.make_counts(n_users_1, n_items, dbar, seed, device=dev, zipf_a=args.zipf, first_user=b * n_users_1)
+             for b in range(world)]
+    ptrs, offset = [parts[0][0][:1]], 0
+    for ip_b, _, _ in parts:
+        ptrs.append(ip_b[1:] + offset)
+        offset += int(ip_b[-1])
+    indptr = torch.cat(ptrs)
+    indices = torch.cat([p[1] for p in parts])
+    counts = torch.cat([p[2] for p in parts])
+    del parts, ptrs
+    nnz = int(indices.numel())
+    eng = AlsEngine(n_users, n_items, k, bias, gamma, device=dev)
+    values = counts.clone()
+    _lib.check(lib.wmf_confidence_transform(ctypes.c_void_p(values.data_ptr()), nnz, 10.0, 1.0, 0,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    eng.set_interactions(indptr, indices, values)
+    from oracle import wmf_oracle as orc            # init only: the legacy-RNG draw of wmf_model.py:10-17
+    eng.set_factors("items", orc.init_items(n_items, k, bias))
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        eng.half_step("users")
+        eng.half_step("items")
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.check_numerics()
+    lib.wmf_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.wmf_profile_enable(0)
+    eng.check_numerics()
+    ms = np.zeros(_lib.WMF_PROF_SLOTS)
+    launches = np.zeros(_lib.WMF_PROF_SLOTS, dtype=np.int64)
+    lib.wmf_profile_read(ms.ctypes.data_as(ctypes.c_void_p), launches.ctypes.data_as(ctypes.c_void_p))
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- eval pass (not part of the timed step; reported separately) ------------------------
+    shard = eng.make_eval_shard(indptr, indices, counts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sq, ab, cnt = eng.eval_sums(shard)
+    torch.cuda.synchronize()
+    t_eval = time.perf_counter() - t0
+
+    # ---- roofline of the dominant kernel (largest total time inside the timed region) ---------
+    f = eng.f
+    kernels = {}
+    for slot in range(_lib.WMF_PROF_SLOTS):
+        if launches[slot]:
+            kernels[lib.wmf_profile_slot_name(slot).decode()] = {
+                "launches": int(launches[slot]), "avg_ms": ms[slot] / launches[slot], "total_ms": float(ms[slot])}
+    n_loc = eng.n_local
+    work = {}          # slot -> (bound, algorithmic units per STEP on this rank)
+    for slot, b in SOLVE_BINS.items():
+        tot = 0
+        for side in ("users", "items"):
+            c = eng.csr[side]
+            rows_b, nnz_b = int(c.bin_rows[b]), int(c.bin_nnz[b])
+            tot += nnz_b * (4 * f + 8) + rows_b * (4 * f + 4)      # gathered + written bytes
+        work[slot] = ("hbm", float(tot))
+    rows_all = n_loc["users"] + n_loc["items"]
+    work[0] = ("mfma", 2.0 * f * f * rows_all)                     # Gramian: 2 m f^2 flops per side
+    work[3] = ("mfma", 2.0 * f * f * 2 * rows_all)                 # whiten + unwhiten GEMMs
+    cand = [s_ for s_ in work if launches[s_] and work[s_][1] > 0]
+    roofline = None
+    if cand:
+        dom = max(cand, key=lambda s_: ms[s_])
+        bound, units_per_step = work[dom]
+        per_launch = units_per_step * args.steps / launches[dom]
+        avg_s = ms[dom] / launches[dom] / 1e3
+        peak, unit, scale = (HBM_PEAK_GBS, "GB/s", 1e9) if bound == "hbm" else (F32_MFMA_PEAK_TF, "TFLOP/s", 1e12)
+        roofline = {"kernel": lib.wmf_profile_slot_name(dom).decode(), "bound": bound,
+                    "achieved": per_launch / avg_s / scale, "peak": peak, "unit": unit,
+                    "frac": per_launch / avg_s / scale / peak, "traffic": None,
+                    "algorithmic_units_per_launch": per_launch, "avg_launch_ms": avg_s * 1e3,
+                    "share_of_step": float(ms[dom] / (elapsed * 1e3))}
+    epoch_bytes = sum(eng.algorithmic_bytes_half(s) for s in ("users", "items"))
+    if world > 1:
+        eb = torch.tensor([epoch_bytes], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(eb)
+        epoch_bytes = float(eb.item())
+
+    out = {
+        "metric": "ALS user+item row-updates/sec", "value": (n_users + n_items) * args.steps / elapsed,
+        "unit": "row-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: WMF k={k}{'+bias' if bias else ''}, {n_users}x{n_items} CSR, "
+                               f"{nnz} nnz, alpha-log confidence, gamma={gamma}, zipf_a={args.zipf}",
+                   "n_users": n_users, "n_items": n_items, "nnz": nnz, "k": k, "bias": bias,
+                   "sharding": f"users+items round-robin over {world} GPU(s)"},
+        "nnz_per_s": 2.0 * nnz * args.steps / elapsed,
+        "epoch_algorithmic_GBps": epoch_bytes * args.steps / elapsed / 1e9,
+        "epoch_hbm_frac": epoch_bytes * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),
+        "roofline": roofline, "kernels": kernels,
+        "eval": {"ms": t_eval * 1e3, "mse": sq / cnt if cnt else None},
+        "setup_s": t_setup,
+        "row_bins": {s: {"rows": eng.csr[s].bin_rows.tolist(), "nnz": eng.csr[s].bin_nnz.tolist()} for s in ("users", "items")},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sample = args.cpu_users or {64: 100_000, 128: 30_000, 16: 943}.get(k, 20_000)
+        sample = min(sample, n_users_1)
+        ip = indptr[: sample + 1].cpu().numpy()
+        mat = synth.to_scipy(indptr[: sample + 1], indices[: ip[-1]], counts[: ip[-1]], (sample, n_items))
+        out["cpu_baseline"] = cpu_baseline(args.config, mat, k, bias, gamma, n_items, sample)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

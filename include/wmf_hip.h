@@ -89,9 +89,9 @@ int wmf_row_transform(const float* in, int64_t m, int f, int ld, const float* W,
 /* Degree-binned schedule for the rows of one CSR matrix (built once per matrix, host indptr). */
 int  wmf_plan_create(const int64_t* indptr_host, int64_t n, int f, wmf_plan** out);
 void wmf_plan_destroy(wmf_plan* p);
-/* Number of rows the plan routes to each kernel family: out[0]=<=16 nnz, [1]=17..32,
- * [2]=MFMA Gramian path, [3]=general LU path. */
-int  wmf_plan_stats(const wmf_plan* p, int64_t* out4);
+/* Rows and stored entries the plan routes to each kernel family: out8[b] = rows, out8[4+b] =
+ * stored entries, for b = 0: <=16 entries, 1: 17..32, 2: MFMA Gramian path, 3: general LU path. */
+int  wmf_plan_stats(const wmf_plan* p, int64_t* out8);
 
 /* The per-row normal-equation solve in whitened coordinates, for every row of the CSR:
  *   g_u = (I + V_u^T D_u V_u)^-1 V_u^T (w_u + 1),   V_u = V[idx_u], D_u = diag(w_u)
@@ -129,6 +129,16 @@ int wmf_spmm_rows(const float* V, const int64_t* indptr, const int32_t* indices,
 /* values[i] = alpha*log(1+beta*values[i]) (mode 0) or alpha*values[i] (mode 1), in place on the
  * device.  wmf_model.py:119-123. */
 int wmf_confidence_transform(float* values, int64_t nnz, double alpha, double beta, int mode, void* stream);
+
+/* ---- per-kernel timing (bench.py roofline) ------------------------------------------------- */
+/* When enabled, every kernel launch of the device-level entry points is bracketed by HIP events
+ * on its own stream.  wmf_profile_read() waits for them and ADDS, per kernel slot, the elapsed
+ * milliseconds and the launch count into ms[WMF_PROF_SLOTS] / launches[WMF_PROF_SLOTS], then
+ * forgets the events.  Slot names: wmf_profile_slot_name(). */
+#define WMF_PROF_SLOTS 12
+int         wmf_profile_enable(int on);
+int         wmf_profile_read(double* ms, int64_t* launches);
+const char* wmf_profile_slot_name(int slot);
 
 #ifdef __cplusplus
 }

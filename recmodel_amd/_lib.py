@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwmf_hip.so")
 
 WMF_OK, WMF_EINVAL, WMF_EHIP, WMF_ENOMEM, WMF_ENUMERIC = 0, -1, -2, -3, -4
+WMF_PROF_SLOTS = 12
 
 c_int, c_i64, c_dbl, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
 
@@ -39,6 +40,9 @@ SIGNATURES = {
     "wmf_predict_pairs": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "wmf_spmm_rows": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "wmf_confidence_transform": (c_int, [c_vp, c_i64, c_dbl, c_dbl, c_int, c_vp]),
+    "wmf_profile_enable": (c_int, [c_int]),
+    "wmf_profile_read": (c_int, [c_vp, c_vp]),
+    "wmf_profile_slot_name": (ctypes.c_char_p, [c_int]),
 }
 
 

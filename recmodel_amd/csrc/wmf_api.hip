@@ -43,27 +43,72 @@ static int check_shape(int f, int ld) {
     return WMF_OK;
 }
 
+// ---- per-kernel event timing ------------------------------------------------------------------
+struct ProfRec { int slot; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static ProfRec g_prof_open;
+static bool g_prof_is_open = false;
+
+void wmf_prof_begin(int slot, hipStream_t st) {
+    if (!g_prof_on) return;
+    ProfRec r; r.slot = slot;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, st);
+    g_prof_open = r; g_prof_is_open = true;
+}
+void wmf_prof_end(hipStream_t st) {
+    if (!g_prof_on || !g_prof_is_open) return;
+    (void)hipEventRecord(g_prof_open.b, st);
+    g_prof.push_back(g_prof_open);
+    g_prof_is_open = false;
+}
+
 extern "C" {
+
+int wmf_profile_enable(int on) { g_prof_on = on != 0; return WMF_OK; }
+int wmf_profile_read(double* ms, int64_t* launches) {
+    for (auto& r : g_prof) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess &&
+            r.slot >= 0 && r.slot < WMF_PROF_SLOTS) {
+            if (ms) ms[r.slot] += t;
+            if (launches) launches[r.slot] += 1;
+        }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return WMF_OK;
+}
+const char* wmf_profile_slot_name(int slot) {
+    static const char* names[WMF_PROF_SLOTS] = {"gram_kernel", "gram_reduce_kernel", "factorize_kernel", "transform_kernel",
+        "solve_low_kernel<.,1>", "solve_low_kernel<.,2>", "solve_general_kernel(heavy)", "solve_general_kernel(fallback)",
+        "eval_kernel", "predict_kernel", "spmm_kernel", "solve_direct_kernel"};
+    return (slot >= 0 && slot < WMF_PROF_SLOTS) ? names[slot] : "?";
+}
 
 const char* wmf_last_error(void) { return g_err; }
 int wmf_version(void) { return 100; }
 int wmf_ld_for(int f) { return (f + 3) & ~3; }
 
-// ---- workspace layout of gram/factorize: [partials fp32][A fp64 f x (f|1)] --------------------
+// ---- workspace layout of gram/factorize: [partials fp32][slices fp64 32 x f x f][A fp64 f x (f|1)] ----
 static int64_t gram_partial_bytes(int f) {
     const int64_t nfb = (f + 15) / 16, nt = nfb * (nfb + 1) / 2;
     return (int64_t)WMF_GRAM_MAX_WAVES * nt * 256 * (int64_t)sizeof(float);
 }
+static int64_t gram_slices_off(int f) { return (gram_partial_bytes(f) + 255) & ~(int64_t)255; }
+static int64_t gram_a_off(int f) { return (gram_slices_off(f) + (int64_t)32 * f * f * 8 + 255) & ~(int64_t)255; }
 int64_t wmf_gram_workspace_bytes(int f) {
     if (f < 1 || f > WMF_MAX_F) return 0;
-    return gram_partial_bytes(f) + (int64_t)f * (f | 1) * (int64_t)sizeof(double) + 256;
+    return gram_a_off(f) + (int64_t)f * (f | 1) * (int64_t)sizeof(double) + 256;
 }
 
 int wmf_gram(const float* Y, int64_t m, int f, int ld, int bias, double* G_sum, void* workspace, void* stream) {
     int rc = check_shape(f, ld);
     if (rc) return rc;
     if (!Y || !G_sum || !workspace || m < 0) { wmf_set_error("wmf_gram: null pointer or negative m"); return WMF_EINVAL; }
-    if (wmf_launch_gram(Y, m, f, ld, bias, G_sum, (float*)workspace, (hipStream_t)stream)) {
+    if (wmf_launch_gram(Y, m, f, ld, bias, G_sum, (float*)workspace, (double*)((char*)workspace + gram_slices_off(f)),
+                        (hipStream_t)stream)) {
         wmf_set_error("wmf_gram: unsupported f=%d", f);
         return WMF_EINVAL;
     }
@@ -75,7 +120,7 @@ int wmf_factorize(const double* G_sum, int f, int ld, double lambda, float* W_wh
     int rc = check_shape(f, ld);
     if (rc) return rc;
     if (!G_sum || !W_white || !W_unwhite || !info || !workspace) { wmf_set_error("wmf_factorize: null pointer"); return WMF_EINVAL; }
-    double* gA = (double*)((char*)workspace + ((gram_partial_bytes(f) + 255) & ~(int64_t)255));
+    double* gA = (double*)((char*)workspace + gram_a_off(f));
     wmf_launch_factorize(G_sum, f, ld, lambda, W_white, W_unwhite, info, gA, (hipStream_t)stream);
     return check_launch("wmf_factorize");
 }
@@ -94,10 +139,9 @@ int wmf_row_transform(const float* in, int64_t m, int f, int ld, const float* W,
 
 // ---- plan ---------------------------------------------------------------------------------------
 static int bin_of(int64_t d, int f) {
-    (void)f;
     if (d <= 16) return WMF_BIN_LOW16;
     if (d <= 32) return WMF_BIN_LOW32;
-    return WMF_BIN_GENERAL;
+    return wmf_direct_supported(f) ? WMF_BIN_MFMA : WMF_BIN_GENERAL;
 }
 
 int wmf_plan_create(const int64_t* indptr, int64_t n, int f, wmf_plan** out) {
@@ -112,6 +156,7 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, wmf_plan** out) {
         const int64_t d = indptr[r + 1] - indptr[r];
         if (d < 0) { delete p; wmf_set_error("wmf_plan_create: indptr not monotone at row %lld", (long long)r); return WMF_EINVAL; }
         p->count[bin_of(d, f)]++;
+        p->nnz[bin_of(d, f)] += d;
     }
     for (int b = 0; b < WMF_NBINS; ++b) start[b + 1] = start[b] + p->count[b];
     int64_t fill[WMF_NBINS];
@@ -141,9 +186,9 @@ void wmf_plan_destroy(wmf_plan* p) {
     delete p;
 }
 
-int wmf_plan_stats(const wmf_plan* p, int64_t* out4) {
-    if (!p || !out4) { wmf_set_error("wmf_plan_stats: null"); return WMF_EINVAL; }
-    for (int b = 0; b < WMF_NBINS; ++b) out4[b] = p->count[b];
+int wmf_plan_stats(const wmf_plan* p, int64_t* out8) {
+    if (!p || !out8) { wmf_set_error("wmf_plan_stats: null"); return WMF_EINVAL; }
+    for (int b = 0; b < WMF_NBINS; ++b) { out8[b] = p->count[b]; out8[WMF_NBINS + b] = p->nnz[b]; }
     return WMF_OK;
 }
 

@@ -79,9 +79,12 @@ __global__ __launch_bounds__(64) void gram_kernel(const float* __restrict__ Y, i
     }
 }
 
-// G_sum[i][j] (fp64) = sum over waves of the partial tile element; symmetric fill.
-__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ partial, int nwaves, int f, int nfb,
-                                                          double* __restrict__ G) {
+// G_sum[i][j] (fp64) = sum over waves of the partial tile element; symmetric fill.  Two stages so
+// that the sum over up to 1024 waves is spread over the chip: stage 1 sums a slice of the waves
+// per (element, slice), stage 2 adds the slices in a fixed order (reproducible).
+#define WMF_GRAM_SLICES 32
+__global__ __launch_bounds__(256) void gram_reduce1_kernel(const float* __restrict__ partial, int nwaves, int f, int nfb,
+                                                           double* __restrict__ slices) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= f * f) return;
     int i = e / f, j = e % f;
@@ -92,8 +95,19 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
     const int lane = cj + 16 * (ri >> 2), reg = ri & 3;
     const int nt = nfb * (nfb + 1) / 2;
     const float* p = partial + ((int64_t)t * 4 + reg) * 64 + lane;
+    const int per = (nwaves + WMF_GRAM_SLICES - 1) / WMF_GRAM_SLICES;
+    const int w0 = blockIdx.y * per, w1 = min(nwaves, w0 + per);
     double s = 0.0;
-    for (int w = 0; w < nwaves; ++w) s += (double)p[(int64_t)w * nt * 256];
+    for (int w = w0; w < w1; ++w) s += (double)p[(int64_t)w * nt * 256];
+    slices[(int64_t)blockIdx.y * f * f + e] = s;
+}
+
+__global__ __launch_bounds__(256) void gram_reduce2_kernel(const double* __restrict__ slices, int f, double* __restrict__ G) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= f * f) return;
+    double s = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < WMF_GRAM_SLICES; ++k) s += slices[(int64_t)k * f * f + e];
     G[e] = s;
 }
 
@@ -118,16 +132,22 @@ int wmf_gram_nwaves(int64_t m) {
     return (int)want;
 }
 
-int wmf_launch_gram(const float* Y, int64_t m, int f, int ld, int bias, double* G_sum, float* partial, hipStream_t st) {
+int wmf_launch_gram(const float* Y, int64_t m, int f, int ld, int bias, double* G_sum, float* partial, double* slices,
+                    hipStream_t st) {
     const int nfb = (f + 15) / 16;
     const int nwaves = wmf_gram_nwaves(m);
+    WmfProfScope* ps = new WmfProfScope(WMF_SLOT_GRAM, st);
     switch (nfb) {
 #define C(N) case N: launch_gram_nfb<N>(Y, m, f, ld, bias, partial, nwaves, st); break;
         C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)
 #undef C
-        default: return -1;
+        default: delete ps; return -1;
     }
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((f * f + 255) / 256), dim3(256), 0, st, partial, nwaves, f, nfb, G_sum);
+    delete ps;
+    WmfProfScope ps2(WMF_SLOT_GRAM_REDUCE, st);
+    hipLaunchKernelGGL(gram_reduce1_kernel, dim3((f * f + 255) / 256, WMF_GRAM_SLICES), dim3(256), 0, st, partial, nwaves,
+                       f, nfb, slices);
+    hipLaunchKernelGGL(gram_reduce2_kernel, dim3((f * f + 255) / 256), dim3(256), 0, st, slices, f, G_sum);
     return 0;
 }
 
@@ -162,9 +182,28 @@ __global__ __launch_bounds__(256) void factorize_kernel(const double* __restrict
         for (int i = k + 1 + t; i < f; i += 256) A[i * lda + k] *= inv;
         if (t == 0) A[k * lda + k] = sk;
         __syncthreads();
-        for (int j = k + 1 + t; j < f; j += 256) {
-            const double ljk = A[j * lda + k];
-            for (int i = j; i < f; ++i) A[i * lda + j] -= A[i * lda + k] * ljk;
+        {
+            // trailing update A[i][j] -= L[i][k] L[j][k], i >= j > k.  P threads share a column
+            // (rows i = j + part, j + part + P, ...); four rows per trip so the LDS reads overlap.
+            const int ncol = f - k - 1;
+            if (ncol > 0) {
+                const int P = ncol >= 256 ? 1 : min(256 / ncol, 8);
+                const int part = t / ncol;
+                for (int j = k + 1 + (t % ncol); j < f && part < P; j += (ncol >= 256 ? 256 : f)) {
+                    const double ljk = A[j * lda + k];
+                    for (int i = j + part; i < f; i += 4 * P) {
+                        const int i1 = i + P, i2 = i + 2 * P, i3 = i + 3 * P;
+                        const double a0 = A[i * lda + k], c0 = A[i * lda + j];
+                        const double a1 = i1 < f ? A[i1 * lda + k] : 0.0, c1 = i1 < f ? A[i1 * lda + j] : 0.0;
+                        const double a2 = i2 < f ? A[i2 * lda + k] : 0.0, c2 = i2 < f ? A[i2 * lda + j] : 0.0;
+                        const double a3 = i3 < f ? A[i3 * lda + k] : 0.0, c3 = i3 < f ? A[i3 * lda + j] : 0.0;
+                        A[i * lda + j] = c0 - a0 * ljk;
+                        if (i1 < f) A[i1 * lda + j] = c1 - a1 * ljk;
+                        if (i2 < f) A[i2 * lda + j] = c2 - a2 * ljk;
+                        if (i3 < f) A[i3 * lda + j] = c3 - a3 * ljk;
+                    }
+                }
+            }
         }
         __syncthreads();
     }
@@ -214,6 +253,7 @@ int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, floa
         (void)hipFuncSetAttribute((const void*)factorize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024 + 16);
         attr_set = true;
     }
+    WmfProfScope ps(WMF_SLOT_FACTORIZE, st);
     hipLaunchKernelGGL(factorize_kernel, dim3(1), dim3(256), (use_lds ? bytes : 0) + 16, st, G_sum, f, ld, lambda, Wwhite,
                        Wunwhite, info, gA, use_lds);
     return 0;
@@ -330,6 +370,7 @@ int wmf_launch_transform(const float* in, int64_t m, int f, int ld, const float*
                          float* col0_out, hipStream_t st) {
     if (m <= 0) return 0;
     const int nfb = (f + 15) / 16;
+    WmfProfScope ps(WMF_SLOT_TRANSFORM, st);
     switch (nfb) {
 #define C(N) case N: launch_transform_nfb<N>(in, m, f, ld, W, set_col0_one, out, col0_out, st); break;
         C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)

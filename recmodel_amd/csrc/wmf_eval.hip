@@ -40,6 +40,7 @@ int wmf_launch_predict(const float* users, const float* items, int f, int ld, in
     if (n <= 0) return 0;
     int64_t grid = (n + 15) / 16;
     if (grid > 8192) grid = 8192;
+    WmfProfScope ps(WMF_SLOT_PREDICT, st);
     hipLaunchKernelGGL(predict_kernel, dim3((unsigned)grid), dim3(256), 0, st, users, items, ld, bias, ui, n_u, ii, n_i,
                        n, out);
     return 0;
@@ -95,6 +96,7 @@ int wmf_launch_eval(const float* users, const float* items, int f, int ld, int b
     int64_t grid = (n + 3) / 4;
     if (grid > WMF_EVAL_MAX_BLOCKS) grid = WMF_EVAL_MAX_BLOCKS;
     if (grid < 1) grid = 1;
+    WmfProfScope ps(WMF_SLOT_EVAL, st);
     hipLaunchKernelGGL(eval_kernel, dim3((unsigned)grid), dim3(256), 0, st, users, items, ld, bias, indptr, indices,
                        values, n, partial);
     hipLaunchKernelGGL(eval_finish_kernel, dim3(1), dim3(64), 0, st, partial, (int)grid, out3);

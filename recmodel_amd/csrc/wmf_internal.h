@@ -13,6 +13,7 @@ struct wmf_plan {
     int64_t n;                 // rows
     int f;
     int64_t count[WMF_NBINS];  // rows per bin
+    int64_t nnz[WMF_NBINS];    // stored entries per bin
     int32_t* rows[WMF_NBINS];  // device: row ids of each bin (slices of rows_all)
     int32_t* rows_all;         // device: n row ids grouped by bin
     int32_t* fallback_rows;    // device: n slots, rows bounced to the general kernel at run time
@@ -20,7 +21,8 @@ struct wmf_plan {
 };
 
 int wmf_gram_nwaves(int64_t m);
-int wmf_launch_gram(const float* Y, int64_t m, int f, int ld, int bias, double* G_sum, float* partial, hipStream_t st);
+int wmf_launch_gram(const float* Y, int64_t m, int f, int ld, int bias, double* G_sum, float* partial, double* slices,
+                    hipStream_t st);
 int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, float* Wwhite, float* Wunwhite,
                          int32_t* info, double* gA, hipStream_t st);
 int wmf_launch_transform(const float* in, int64_t m, int f, int ld, const float* W, int set_col0_one, float* out,
@@ -29,6 +31,10 @@ int wmf_launch_transform(const float* in, int64_t m, int f, int ld, const float*
 int wmf_launch_solve(const wmf_plan* plan, const float* V, const float* bias_fixed, const int64_t* indptr,
                      const int32_t* indices, const float* values, int f, int ld, float* g, int32_t* fail_count,
                      hipStream_t st);
+int wmf_direct_supported(int f);
+int wmf_launch_direct(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
+                      const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
+                      int32_t* fb_count, hipStream_t st);
 int wmf_launch_spmm(const float* V, const int64_t* indptr, const int32_t* indices, const float* values, int64_t n,
                     int ld, float* g, hipStream_t st);
 int wmf_launch_eval(const float* users, const float* items, int f, int ld, int bias, const int64_t* indptr,
@@ -39,3 +45,17 @@ int wmf_launch_predict(const float* users, const float* items, int f, int ld, in
 int wmf_launch_confidence(float* values, int64_t nnz, double alpha, double beta, int mode, hipStream_t st);
 
 void wmf_set_error(const char* fmt, ...);
+
+// per-kernel event timing (wmf_api.hip)
+enum {
+    WMF_SLOT_GRAM = 0, WMF_SLOT_GRAM_REDUCE, WMF_SLOT_FACTORIZE, WMF_SLOT_TRANSFORM, WMF_SLOT_SOLVE_LOW16,
+    WMF_SLOT_SOLVE_LOW32, WMF_SLOT_SOLVE_HEAVY, WMF_SLOT_SOLVE_FALLBACK, WMF_SLOT_EVAL, WMF_SLOT_PREDICT,
+    WMF_SLOT_SPMM, WMF_SLOT_SOLVE_DIRECT
+};
+void wmf_prof_begin(int slot, hipStream_t st);
+void wmf_prof_end(hipStream_t st);
+struct WmfProfScope {
+    hipStream_t st;
+    WmfProfScope(int slot, hipStream_t s) : st(s) { wmf_prof_begin(slot, s); }
+    ~WmfProfScope() { wmf_prof_end(st); }
+};

@@ -17,8 +17,45 @@
 #include "wmf_common.h"
 #include "wmf_internal.h"
 
+#include <utility>
+
 __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// One Gauss-Jordan step on pivot K (compile time, so register indices and the DPP control are
+// static).  Row j is spread over the 4 lanes (r, q = 0..3); column K lives in lanes q = (K & 15) >> 2,
+// register (K >> 4) * 4 + (K & 3).
+template <int K, int NSETS>
+__device__ __forceinline__ void gj_step(float (&m)[NSETS][NSETS * 4], float (&p)[NSETS], int d, int lane, bool& bad) {
+    if (K < d) {                                    // d is wave-uniform
+        constexpr int DPP_ROW_NEWBCAST = 0x150;     // gfx90a+: lane n of each 16-lane row to the whole row
+        constexpr int ks = K >> 4, kk = K & 15, kq = kk >> 2, kreg = ks * 4 + (kk & 3);
+        const int r = lane & 15;
+        const float piv = readlane_f(m[ks][kreg], kk + 16 * kq);
+        if (!(piv > 0.25f)) bad = true;
+        const float inv = __builtin_amdgcn_rcpf(piv);
+        float pr[NSETS * 4];
+#pragma unroll
+        for (int c = 0; c < NSETS * 4; ++c) pr[c] = wmf_dpp<DPP_ROW_NEWBCAST + kk>(m[ks][c]) * inv;
+        const float pk = readlane_f(p[ks], kk) * inv;
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s) {
+            // multiplier M[j][K]; for the pivot row itself use piv - 1, which turns row - f * (row * inv)
+            // into row * inv (the normalised pivot row) without a select per element
+            float fk = __shfl(m[s][kreg], r + 16 * kq);
+            if (s == ks) fk = (r == kk) ? piv - 1.f : fk;
+#pragma unroll
+            for (int c = 0; c < NSETS * 4; ++c) m[s][c] -= fk * pr[c];
+            p[s] -= fk * pk;
+        }
+    }
+}
+
+template <int NSETS, int... Ks>
+__device__ __forceinline__ void gj_sweep(float (&m)[NSETS][NSETS * 4], float (&p)[NSETS], int d, int lane, bool& bad,
+                                         std::integer_sequence<int, Ks...>) {
+    (gj_step<Ks, NSETS>(m, p, d, lane, bad), ...);
 }
 
 // ------------------------------------------------------------------------------ low-degree rows
@@ -100,27 +137,7 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
     //      Row j is spread over the 4 lanes (r, q = 0..3); column k lives in lanes q = (k & 15) >> 2,
     //      register (k >> 4) * 4 + (k & 3).  After the sweep M = I and p = M^-1 p = c.
     bool bad = false;
-#pragma unroll
-    for (int k = 0; k < 16 * NSETS; ++k) {
-        if (k < d) {                                // d is wave-uniform
-            const int ks = k >> 4, kk = k & 15, kq = kk >> 2, kreg = ks * 4 + (kk & 3);
-            const float piv = readlane_f(m[ks][kreg], kk + 16 * kq);
-            if (!(piv > 0.25f)) bad = true;
-            const float inv = 1.f / piv;
-            float pr[NSETS * 4];
-#pragma unroll
-            for (int c = 0; c < NSETS * 4; ++c) pr[c] = __shfl(m[ks][c], (lane & 48) | kk) * inv;
-            const float pk = readlane_f(p[ks], kk) * inv;
-#pragma unroll
-            for (int s = 0; s < NSETS; ++s) {
-                const float fk = __shfl(m[s][kreg], r + 16 * kq);
-                const bool is_piv = (s == ks) && (r == kk);
-#pragma unroll
-                for (int c = 0; c < NSETS * 4; ++c) m[s][c] = is_piv ? pr[c] : (m[s][c] - fk * pr[c]);
-                p[s] = is_piv ? pk : (p[s] - fk * pk);
-            }
-        }
-    }
+    gj_sweep<NSETS>(m, p, d, lane, bad, std::make_integer_sequence<int, 16 * NSETS>{});
     if (bad) {                                      // uniform (piv is a scalar)
         if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;
         return;
@@ -296,6 +313,7 @@ int wmf_launch_spmm(const float* V, const int64_t* indptr, const int32_t* indice
     if (n <= 0) return 0;
     int64_t grid = (n + 3) / 4;
     if (grid > 8192) grid = 8192;
+    WmfProfScope ps(WMF_SLOT_SPMM, st);
     hipLaunchKernelGGL(spmm_kernel, dim3((unsigned)grid), dim3(256), 0, st, V, indptr, indices, values, n, ld, g);
     return 0;
 }
@@ -305,14 +323,18 @@ template <int NCH>
 static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int ld, float* g, hipStream_t st) {
     const int64_t c0 = pl->count[WMF_BIN_LOW16], c1 = pl->count[WMF_BIN_LOW32];
-    if (c0 > 0)
+    if (c0 > 0) {
+        WmfProfScope ps(WMF_SLOT_SOLVE_LOW16, st);
         hipLaunchKernelGGL((solve_low_kernel<NCH, 1>), dim3((unsigned)((c0 + 3) / 4)), dim3(256), 0, st,
                            pl->rows[WMF_BIN_LOW16], c0, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
                            pl->fallback_count);
-    if (c1 > 0)
+    }
+    if (c1 > 0) {
+        WmfProfScope ps(WMF_SLOT_SOLVE_LOW32, st);
         hipLaunchKernelGGL((solve_low_kernel<NCH, 2>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
                            pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
                            pl->fallback_count);
+    }
 }
 
 template <int NFB>
@@ -354,16 +376,22 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
         default: return -1;
     }
     const bool general_ok = f <= 144;
-    const int64_t heavy = pl->count[WMF_BIN_MFMA] + pl->count[WMF_BIN_GENERAL];
-    if (heavy > 0) {
+    if (pl->count[WMF_BIN_MFMA] > 0) {
+        WmfProfScope ps(WMF_SLOT_SOLVE_DIRECT, st);
+        if (wmf_launch_direct(pl->rows[WMF_BIN_MFMA], pl->count[WMF_BIN_MFMA], V, biasv, indptr, indices, vals, f, ld, g,
+                              pl->fallback_rows, pl->fallback_count, st)) return -1;
+    }
+    if (pl->count[WMF_BIN_GENERAL] > 0) {
         if (!general_ok) return -1;
-        // the two heavy bins are adjacent in rows_all
+        const int64_t heavy = pl->count[WMF_BIN_GENERAL];
         int grid = (int)(heavy < 4096 ? heavy : 4096);
-        if (dispatch_general(pl->rows[WMF_BIN_MFMA], heavy, nullptr, grid, V, biasv, indptr, indices, vals, f, ld, g,
+        WmfProfScope ps(WMF_SLOT_SOLVE_HEAVY, st);
+        if (dispatch_general(pl->rows[WMF_BIN_GENERAL], heavy, nullptr, grid, V, biasv, indptr, indices, vals, f, ld, g,
                              fail_count, st)) return -1;
     }
-    if (general_ok && pl->count[WMF_BIN_LOW16] + pl->count[WMF_BIN_LOW32] > 0) {
-        // rows bounced by the low-degree kernels (negative weights / bad pivot); count is on the device
+    if (general_ok) {
+        // rows bounced by the other kernels (negative weights / not positive definite); count is on the device
+        WmfProfScope ps(WMF_SLOT_SOLVE_FALLBACK, st);
         if (dispatch_general(pl->fallback_rows, 0, pl->fallback_count, 256, V, biasv, indptr, indices, vals, f, ld, g,
                              fail_count, st)) return -1;
     }

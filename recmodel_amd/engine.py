@@ -49,9 +49,9 @@ class Csr:
         handle = ctypes.c_void_p()
         _lib.check(lib.wmf_plan_create(host_ptr.ctypes.data_as(ctypes.c_void_p), self.n_rows, f, ctypes.byref(handle)))
         self._plan = handle
-        stats = np.zeros(4, dtype=np.int64)
+        stats = np.zeros(8, dtype=np.int64)
         _lib.check(lib.wmf_plan_stats(self._plan, stats.ctypes.data_as(ctypes.c_void_p)))
-        self.bin_counts = stats
+        self.bin_rows, self.bin_nnz = stats[:4].copy(), stats[4:].copy()
 
     def __del__(self):
         plan, self._plan = getattr(self, "_plan", None), None

@@ -1,0 +1,302 @@
+"""Parity of the HIP path against (a) golden vectors captured from the reference WMF class and
+(b) the CPU oracle on seeded inputs.  Everything here calls through the C ABI of libwmf_hip.so.
+
+Stated fp32 tolerance (DESIGN.md "Numerics"): the reference computes each row system in float64
+when the count matrix is float64 and stores float32; the HIP path computes in float32 on
+whitened factors.  Its error is bounded by ~cond(A_u) * eps_f32:
+  * one half step from identical inputs:  relative Frobenius error <= 5e-5, worst row <= 5e-4
+    (the worst case is the bias model at its uniform(0,1) initialisation, cond(G) ~ 1e4);
+  * after T >= 2 iterations: relative Frobenius error <= 1e-3, |dMSE|/MSE <= 1e-4.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import csr_from, load_golden
+from oracle import wmf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+HALF_FRO, HALF_ROW = 5e-5, 5e-4
+TRAIN_FRO, TRAIN_MSE = 1e-3, 1e-4
+
+
+def fro(a, b):
+    return np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def worst_row(a, b):
+    num = np.linalg.norm(a.astype(np.float64) - b, axis=1)
+    den = np.linalg.norm(b, axis=1)
+    ok = den > 0
+    return (num[ok] / den[ok]).max() if ok.any() else 0.0, (num[~ok].max() if (~ok).any() else 0.0)
+
+
+@pytest.fixture(scope="module")
+def WMF():
+    from recmodel_amd import WMF as cls, _lib
+    _lib.load()
+    return cls
+
+
+# ------------------------------------------------------------------ golden vectors of the reference
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("cdt", ["float32", "float64"])
+def test_half_steps_match_reference_golden(WMF, bias, cdt):
+    g = load_golden(f"half_bias{int(bias)}_{cdt}.npz")
+    C, CT = csr_from(g, "C"), csr_from(g, "CT")
+    m = WMF(num_items=C.shape[1], num_users=C.shape[0], dim=16, gamma=0.1, weighted=True, bias=bias)
+    step = m.recompute_factors_bias if bias else m.recompute_factors
+    for Y, mat, want in ((g["items0"], C, g["users1"]), (g["users1"], CT, g["items1"]), (g["items1"], C, g["users2"])):
+        got = step(Y, mat, 0.1)
+        assert got.dtype == np.float32 and got.shape == want.shape
+        assert fro(got, want) <= HALF_FRO
+        rel, zero_abs = worst_row(got, want)
+        assert rel <= HALF_ROW and zero_abs == 0.0      # rows without stored entries are exactly zero
+    assert np.all(step(g["items0"], C, 0.1)[3] == 0)    # the fixture's empty user row
+
+
+@pytest.mark.parametrize("tag,bias", [("run", False), ("stop", False), ("bias", True)])
+def test_train_matches_reference_golden(WMF, tag, bias, capsys):
+    g = load_golden(f"train_{tag}.npz")
+    counts, util = csr_from(g, "counts"), csr_from(g, "util")
+    m = WMF(num_items=util.shape[1], num_users=util.shape[0], dim=int(g["dim"]), gamma=0.1, weighted=True, bias=bias)
+    hist = []
+    inner = m.eval_prec
+    last = m.train(utility_mat=util, iterations=int(g["iterations"]), eval_mat=util, count_mat=counts, cores=1,
+                   stopping_rounds=int(g["stopping_rounds"]), min_improvement=float(g["min_improvement"]))
+    out = capsys.readouterr().out
+    assert last == int(g["last_iter"])                               # early-stop control flow (wmf_model.py:164-180)
+    assert ("took" in out) == bias                                   # the bias path prints per-iteration time (:153)
+    assert m.users.dtype == np.float32 and m.items.dtype == np.float32
+    assert fro(m.users, g["users"]) <= TRAIN_FRO and fro(m.items, g["items"]) <= TRAIN_FRO
+    mse = inner(util)
+    assert abs(mse - float(g["mse_final"])) <= TRAIN_MSE * float(g["mse_final"])
+    assert abs(m.eval_prec(util, "rmse") - float(g["rmse_final"])) <= TRAIN_MSE * float(g["rmse_final"])
+    assert abs(m.eval_prec(util, "mae") - float(g["mae_final"])) <= TRAIN_MSE * float(g["mae_final"])
+    with pytest.raises(ValueError):
+        m.eval_prec(util, "auc")
+
+
+def test_predict_rank_on_reference_factors(WMF):
+    for tag, bias in (("run", False), ("bias", True)):
+        g = load_golden(f"train_{tag}.npz")
+        util = csr_from(g, "util")
+        m = WMF(num_items=util.shape[1], num_users=util.shape[0], dim=int(g["dim"]), gamma=0.1, weighted=True, bias=bias)
+        m.users, m.items = g["users"], g["items"]                    # the reference's own final factors
+        np.testing.assert_allclose(m.predict(g["pred_users"], g["pred_items"]), g["pred"], rtol=2e-6, atol=2e-6)
+        cand = g["rank_cand"]
+        np.testing.assert_allclose(m.predict(np.array([7]), cand), g["pred_one_user"], rtol=2e-6, atol=2e-6)
+        with pytest.raises(ValueError):      # the reference's length check only lets ONE USER broadcast (wmf_model.py:202)
+            m.predict([3, 4, 5], [9])
+        np.testing.assert_allclose(m.predict([3], [9, 10, 11]), orc.predict(m.users, m.items, [3, 3, 3], [9, 10, 11], bias), rtol=2e-6, atol=2e-6)
+        # rank: tie order is implementation defined -> compare the scores of the returned ids
+        sc = dict(zip(cand.tolist(), g["pred_one_user"].tolist()))
+        for topn, key in ((5, "rank_top5"), (40, "rank_top40"), (None, "rank_all")):
+            got = m.rank(cand, 7, topn=topn)
+            assert len(got) == len(g[key])
+            np.testing.assert_allclose([sc[i] for i in got], [sc[i] for i in g[key]], rtol=1e-5, atol=1e-6)
+        lst = m.rank(cand, [1, 2], topn=3)
+        assert isinstance(lst, list) and len(lst) == 2
+        with pytest.raises(ValueError):
+            m.predict(np.array([0, 1]), np.array([0, 1, 2]))
+        np.testing.assert_allclose(m.eval_prec(util), float(g["mse_final"]), rtol=1e-5)
+
+
+def test_unweighted_branch_matches_reference_golden(WMF):
+    g = load_golden("train_unweighted.npz")
+    util = csr_from(g, "util")
+    m = WMF(num_items=util.shape[1], num_users=util.shape[0], dim=10, gamma=0.5, seed=1993)
+    last = m.train(utility_mat=util, iterations=2, eval_mat=util, stopping_rounds=5)
+    assert last == int(g["last_iter"]) and m.users.dtype == np.float64
+    assert fro(m.users, g["users"]) <= 1e-4 and fro(m.items, g["items"]) <= 1e-4
+    assert abs(m.eval_prec(util) - float(g["mse_final"])) <= 1e-4 * float(g["mse_final"])
+
+
+# ------------------------------------------------------------------ oracle on seeded inputs
+def as_f64(mat):
+    """float64 copy that keeps the stored structure (scipy's astype() merges duplicate entries)."""
+    return sp.csr_matrix((mat.data.astype(np.float64), mat.indices.copy(), mat.indptr.copy()), shape=mat.shape)
+
+
+def ragged_matrix(n, m, seed, dtype=np.float32):
+    """Rows of degree 0,1,16,17,32,33,100,max plus a Poisson body; one stored zero; one duplicate."""
+    from recmodel_amd import synth
+    rng = np.random.default_rng(seed)
+    ip, idx, val = synth.make_counts(n, m, 11, seed)
+    C = synth.to_scipy(ip, idx, val, (n, m)).tolil()
+    for r, d in {0: 0, 1: 1, 2: 16, 3: 17, 4: 32, 5: 33, 6: 100, 7: m, 8: 2, 9: 31}.items():
+        cols = np.sort(rng.choice(m, d, replace=False))
+        C.rows[r] = list(cols)
+        C.data[r] = list((2 + rng.integers(0, 5, d)).astype(dtype))
+    C = C.tocsr().astype(dtype)
+    C.data = (10 * np.log(1 + C.data)).astype(dtype)
+    C.data[C.indptr[8]] = 0.0                                         # stored zero still contributes (w+1)*y
+    # non-canonical CSR: append a duplicate of row 9's first entry at the end of row 9
+    lo, hi = C.indptr[9], C.indptr[10]
+    indices = np.concatenate([C.indices[:hi], C.indices[lo:lo + 1], C.indices[hi:]])
+    data = np.concatenate([C.data[:hi], C.data[lo:lo + 1], C.data[hi:]])
+    indptr = C.indptr.copy(); indptr[10:] += 1
+    D = sp.csr_matrix((data, indices, indptr), shape=C.shape)
+    assert D.nnz == C.nnz + 1
+    return D
+
+
+@pytest.mark.parametrize("k,bias", [(16, False), (64, False), (64, True), (128, False), (128, True), (50, False), (33, True)])
+def test_half_step_vs_oracle_all_degree_classes(WMF, k, bias):
+    n, m_items = 2500, 600
+    C = ragged_matrix(n, m_items, seed=k + bias)
+    model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=bias)
+    # one oracle iteration first so the factors are "trained-like" rather than uniform noise
+    step_o = orc.recompute_factors_bias if bias else orc.recompute_factors
+    step_g = model.recompute_factors_bias if bias else model.recompute_factors
+    C64, CT = as_f64(C), C.T.tocsr()
+    for Y, mat in ((model.items, C), (step_o(model.items, C64, 0.1), CT)):
+        want = step_o(Y, as_f64(mat), 0.1, out_dtype="float64")
+        got = step_g(Y, mat, 0.1)
+        rel, zero_abs = worst_row(got, want)
+        assert fro(got, want) <= HALF_FRO, (k, bias, fro(got, want))
+        assert rel <= HALF_ROW and zero_abs == 0.0, (k, bias, rel, zero_abs)
+        assert not np.isnan(got).any()
+
+
+def test_negative_weights_take_the_pivoted_path(WMF):
+    """bias model with large fixed-side biases: w - bias < 0 for many entries, so A_u is not SPD
+     and the rows must go through the LU kernel."""
+    n, m_items, k = 400, 150, 16
+    C = ragged_matrix(n, m_items, seed=77)
+    model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=True)
+    Y = model.items.copy()
+    Y[:, 0] = np.linspace(-5, 40, m_items)                            # weights are ~7..18: about half go negative
+    want = orc.recompute_factors_bias(Y, as_f64(C), 0.1, out_dtype="float64")
+    got = model.recompute_factors_bias(Y, C, 0.1)
+    ok = np.linalg.norm(want, axis=1) < 1e3                           # skip rows that are themselves near singular
+    assert ok.mean() > 0.9
+    assert fro(got[ok], want[ok]) <= 1e-3
+    assert not np.isnan(got).any()
+
+
+def test_full_training_vs_oracle(WMF):
+    from recmodel_amd import synth
+    n, m_items, k = 1500, 400, 32
+    ip, idx, val = synth.make_counts(n, m_items, 9, seed=4)
+    counts = synth.to_scipy(ip, idx, val, (n, m_items)).astype(np.float64)
+    for bias in (False, True):
+        model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=bias)
+        last = model.train(utility_mat=counts, iterations=3, eval_mat=counts, count_mat=counts, cores=2, stopping_rounds=5)
+        r_last, r_hist, r_users, r_items = orc.train(m_items, n, k, 0.1, counts, 3, counts, count_mat=counts,
+                                                     weighted=True, bias=bias, stopping_rounds=5)
+        assert last == r_last == 2
+        assert fro(model.users, r_users) <= TRAIN_FRO and fro(model.items, r_items) <= TRAIN_FRO
+        assert abs(model.eval_prec(counts) - r_hist[-1]) <= TRAIN_MSE * r_hist[-1]
+        # top-10 overlap on sampled users
+        cand = np.arange(m_items)
+        overlap = []
+        for u in range(0, n, 97):
+            a = set(model.rank(cand, u, topn=10).tolist())
+            b = set(orc.rank(r_users, r_items, cand, u, 10, bias).tolist())
+            overlap.append(len(a & b) / 10)
+        assert np.mean(overlap) >= 0.99
+
+
+def test_train_argument_errors_like_reference(WMF):
+    c = sp.random(30, 20, density=0.3, format="csr", random_state=1)
+    m = WMF(num_items=20, num_users=30, dim=4, gamma=0.1, weighted=True)
+    with pytest.raises(ValueError):
+        m.train(utility_mat=c, iterations=1, eval_mat=c, count_mat=c, pre_process_count="sqrt")
+    with pytest.raises(ValueError):
+        m.train(utility_mat=c, iterations=1, eval_mat=c, count_mat=c, cores=0)
+    with pytest.raises(AttributeError):
+        m.train(utility_mat=c, iterations=1, eval_mat=None, count_mat=c)      # wmf_model.py:61-63
+
+
+# ------------------------------------------------------------------ size-independent properties at bench scale
+def test_properties_at_benchmark_scale():
+    """cfg2-shaped matrix (k=64, ~2 M stored entries here; the bench runs the 20 M version): every
+    updated row must satisfy its own normal equations, empty rows must be zero, and the weighted
+    loss must not increase across half steps."""
+    from recmodel_amd import synth
+    from recmodel_amd.engine import AlsEngine
+    n_users, n_items, k = 100_000, 10_000, 64
+    ip, idx, val = synth.make_counts(n_users, n_items, 20, seed=1995, device="cuda")
+    val = 10 * torch.log(1 + val)
+    eng = AlsEngine(n_users, n_items, k, False, 0.1)
+    eng.set_interactions(ip, idx, val)
+    eng.set_factors("items", orc.init_items(n_items, k))
+    C = synth.to_scipy(ip, idx, val, (n_users, n_items))
+
+    def weighted_loss(X, Y):
+        # sum_ui c_ui (p_ui - x.y)^2 over stored entries + implicit zeros + ridge (Hu/Koren/Volinsky objective)
+        rows = np.repeat(np.arange(n_users), np.diff(C.indptr))
+        s = np.einsum("ij,ij->i", X[rows], Y[C.indices])
+        stored = ((C.data + 1) * (1 - s) ** 2 - s ** 2).sum()
+        all_pairs = np.trace((X.T @ X) @ (Y.T @ Y))
+        return stored + all_pairs + 0.1 * ((X ** 2).sum() + (Y ** 2).sum())
+
+    losses = []
+    for it in range(2):
+        eng.half_step("users")
+        X, Y = eng.get_factors("users").astype(np.float64), eng.get_factors("items").astype(np.float64)
+        losses.append(weighted_loss(X, Y))
+        eng.half_step("items")
+        X, Y = eng.get_factors("users").astype(np.float64), eng.get_factors("items").astype(np.float64)
+        losses.append(weighted_loss(X, Y))
+    eng.check_numerics()
+    assert all(b <= a * (1 + 1e-6) for a, b in zip(losses, losses[1:])), losses
+    # normal-equation residual of sampled item rows against the users that produced them
+    CT = C.T.tocsr()
+    G = X.T @ X + 0.1 * np.eye(k)
+    worst = 0.0
+    for i in np.random.default_rng(0).choice(n_items, 200, replace=False):
+        lo, hi = CT.indptr[i], CT.indptr[i + 1]
+        U, w = X[CT.indices[lo:hi]], CT.data[lo:hi].astype(np.float64)
+        A, b = G + U.T @ (U * w[:, None]), (w + 1) @ U
+        worst = max(worst, np.linalg.norm(A @ Y[i] - b) / max(np.linalg.norm(b), 1e-30))
+    assert worst <= 2e-4, worst
+
+
+def test_device_building_blocks_individually():
+    """gram / factorize / row_transform against NumPy, including a non-positive-definite Gramian."""
+    from recmodel_amd import _lib
+    from recmodel_amd.engine import _ptr, _stream
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for f, bias in ((7, 0), (64, 0), (129, 1), (200, 0), (257, 1)):
+        ld = lib.wmf_ld_for(f)
+        m = 1234
+        Y = rng.standard_normal((m, f)).astype(np.float32)
+        Yd = torch.zeros(m, ld, device="cuda"); Yd[:, :f] = torch.from_numpy(Y).cuda()
+        ws = torch.empty(int(lib.wmf_gram_workspace_bytes(f)), dtype=torch.uint8, device="cuda")
+        G = torch.zeros(f * f, dtype=torch.float64, device="cuda")
+        _lib.check(lib.wmf_gram(_ptr(Yd), m, f, ld, bias, _ptr(G), _ptr(ws), _stream()))
+        Yt = Y.astype(np.float64).copy()
+        if bias:
+            Yt[:, 0] = 1
+        Gref = Yt.T @ Yt
+        np.testing.assert_allclose(G.cpu().numpy().reshape(f, f), Gref, rtol=0, atol=2e-6 * np.abs(Gref).max())
+        Ww, Wu = torch.zeros(f, ld, device="cuda"), torch.zeros(f, ld, device="cuda")
+        info = torch.zeros(4, dtype=torch.int32, device="cuda")
+        _lib.check(lib.wmf_factorize(_ptr(G), f, ld, 0.1, _ptr(Ww), _ptr(Wu), _ptr(info), _ptr(ws), _stream()))
+        assert int(info[0]) == 0
+        Linv = np.linalg.inv(np.linalg.cholesky(G.cpu().numpy().reshape(f, f) + 0.1 * np.eye(f)))
+        np.testing.assert_allclose(Wu.cpu().numpy()[:, :f], Linv, rtol=0, atol=1e-6 * np.abs(Linv).max())
+        np.testing.assert_allclose(Ww.cpu().numpy()[:, :f], Linv.T, rtol=0, atol=1e-6 * np.abs(Linv).max())
+        V = torch.full((m, ld), 3.0, device="cuda")
+        bv = torch.zeros(m, device="cuda")
+        _lib.check(lib.wmf_row_transform(_ptr(Yd), m, f, ld, _ptr(Ww), bias, _ptr(V), _ptr(bv) if bias else None, _stream()))
+        Vref = Yt @ Linv.T
+        np.testing.assert_allclose(V.cpu().numpy()[:, :f], Vref, rtol=0, atol=3e-6 * np.abs(Vref).max() * np.sqrt(f))
+        assert np.all(V.cpu().numpy()[:, f:] == 0)
+        if bias:
+            np.testing.assert_array_equal(bv.cpu().numpy(), Y[:, 0])
+    # not positive definite -> info > 0, no exception inside the kernel, zero transforms
+    f, ld = 8, 8
+    G = torch.from_numpy(-np.eye(f).reshape(-1)).cuda()
+    Ww, Wu = torch.ones(f, ld, device="cuda"), torch.ones(f, ld, device="cuda")
+    info = torch.zeros(4, dtype=torch.int32, device="cuda")
+    ws = torch.empty(int(lib.wmf_gram_workspace_bytes(f)), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.wmf_factorize(_ptr(G), f, ld, 0.1, _ptr(Ww), _ptr(Wu), _ptr(info), _ptr(ws), _stream()))
+    assert int(info[0]) == 1 and float(Ww.abs().sum()) == 0.0

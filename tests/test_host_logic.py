@@ -1,0 +1,60 @@
+"""CPU-only tests of the host layer above the C ABI: constructor parity with the reference's RNG
+draw, the synthetic generator, id<->position sharding maps, and early-stop bookkeeping."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from recmodel_amd import WMF, synth
+from recmodel_amd.engine import coo_to_csr
+
+
+def test_constructor_draws_like_reference():
+    g = load_golden("init.npz")
+    for bias, key in ((False, "items_bias0"), (True, "items_bias1")):
+        m = WMF(num_items=37, num_users=5, dim=6, gamma=0.1, weighted=True, bias=bias, seed=1993)
+        np.testing.assert_array_equal(m.items, g[key])
+        assert m.users is None and m.dim == 6 and m.num_items == 37 and m.dtype == 'float32'
+    m = WMF(num_items=9, num_users=5, dim=4, gamma=0.1, weighted=True, seed=7)
+    np.testing.assert_array_equal(m.items, g["items_seed7"])
+
+
+def test_synth_generator_shapes_and_determinism():
+    a = synth.make_counts(500, 80, 7, seed=3)
+    b = synth.make_counts(500, 80, 7, seed=3)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    indptr, idx, val = a
+    assert indptr[0] == 0 and indptr[-1] == idx.numel() == val.numel()
+    deg = indptr[1:] - indptr[:-1]
+    assert deg.min() >= 1 and abs(deg.float().mean().item() - 7) < 1.0
+    assert val.min() >= 2 and idx.max() < 80
+    m = synth.to_scipy(indptr, idx, val, (500, 80))
+    assert m.has_sorted_indices and m.nnz == idx.numel()
+    m.sum_duplicates()
+    assert m.nnz == idx.numel()                       # no duplicates inside a row
+    z = synth.make_counts(300, 2000, 5, seed=3, zipf_a=1.0)
+    pop = torch.bincount(z[1], minlength=2000)
+    assert pop[:20].sum() > pop[-200:].sum()          # skewed towards the head
+
+
+def test_coo_to_csr_keeps_duplicates_and_order():
+    rows = torch.tensor([2, 0, 2, 2, 1])
+    cols = torch.tensor([1, 3, 1, 0, 2])
+    vals = torch.tensor([1., 2., 3., 4., 5.])
+    indptr, idx, v = coo_to_csr(rows, cols, vals, 4)
+    assert indptr.tolist() == [0, 1, 2, 5, 5]
+    assert idx.tolist() == [3, 2, 0, 1, 1]
+    assert v.tolist() == [2., 5., 4., 1., 3.]         # stable: the duplicate (2,1) keeps its stored order
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_round_robin_positions_are_a_bijection(world):
+    n = 103
+    rpr = (n + world - 1) // world
+    ids = np.arange(n)
+    pos = (ids % world) * rpr + ids // world
+    assert len(set(pos.tolist())) == n and pos.max() < world * rpr
+    for r in range(world):
+        mine = ids[r::world]
+        np.testing.assert_array_equal(pos[mine], r * rpr + np.arange(len(mine)))   # contiguous block per rank

@@ -59,7 +59,7 @@ ipd = torch.from_numpy(C.indptr.astype(np.int64)).to(dev); idxd = torch.from_num
 vald = torch.from_numpy(C.data).to(dev)
 hp = np.ascontiguousarray(C.indptr, dtype=np.int64)
 plan = ctypes.c_void_p(); _lib.check(lib.wmf_plan_create(hp.ctypes.data_as(ctypes.c_void_p), n, f, ctypes.byref(plan)))
-st4 = np.zeros(4, np.int64); lib.wmf_plan_stats(plan, st4.ctypes.data_as(ctypes.c_void_p)); print("plan bins", st4)
+st4 = np.zeros(8, np.int64); lib.wmf_plan_stats(plan, st4.ctypes.data_as(ctypes.c_void_p)); print("plan bins", st4)
 g = torch.full((n, ld), 5.0, device=dev); fail = torch.zeros(4, dtype=torch.int32, device=dev)
 t0 = time.time()
 _lib.check(lib.wmf_solve_rows(plan, _ptr(V), _ptr(bvec) if bias else None, _ptr(ipd), _ptr(idxd), _ptr(vald), n, f, ld, _ptr(g), _ptr(fail), _stream()))
@@ -69,7 +69,8 @@ _lib.check(lib.wmf_row_transform(_ptr(g), n, f, ld, _ptr(Wu), 0, _ptr(X), None, 
 torch.cuda.synchronize()
 Xh = X.cpu().numpy()[:, :f]
 step = orc.recompute_factors_bias if bias else orc.recompute_factors
-Xref = step(Y, C.astype(np.float64), lam, out_dtype='float64')
+import scipy.sparse as sp
+Xref = step(Y, sp.csr_matrix((C.data.astype(np.float64), C.indices, C.indptr), shape=C.shape), lam, out_dtype='float64')
 deg = np.diff(C.indptr)
 num = np.linalg.norm(Xh - Xref, axis=1); den = np.linalg.norm(Xref, axis=1) + 1e-30
 rel = num / den
