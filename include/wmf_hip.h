@@ -139,6 +139,8 @@ int wmf_confidence_transform(float* values, int64_t nnz, double alpha, double be
 int         wmf_profile_enable(int on);
 int         wmf_profile_read(double* ms, int64_t* launches);
 const char* wmf_profile_slot_name(int slot);
+/* Kernel-ablation switches for timing experiments (results are WRONG when non-zero); default 0. */
+int         wmf_debug_set_flags(int flags);
 
 #ifdef __cplusplus
 }

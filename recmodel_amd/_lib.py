@@ -41,6 +41,7 @@ SIGNATURES = {
     "wmf_spmm_rows": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "wmf_confidence_transform": (c_int, [c_vp, c_i64, c_dbl, c_dbl, c_int, c_vp]),
     "wmf_profile_enable": (c_int, [c_int]),
+    "wmf_debug_set_flags": (c_int, [c_int]),
     "wmf_profile_read": (c_int, [c_vp, c_vp]),
     "wmf_profile_slot_name": (ctypes.c_char_p, [c_int]),
 }

@@ -10,6 +10,7 @@
 #include <vector>
 
 static thread_local char g_err[512] = "";
+int wmf_debug_flags = 0;
 
 void wmf_set_error(const char* fmt, ...) {
     va_list ap;
@@ -66,6 +67,7 @@ void wmf_prof_end(hipStream_t st) {
 
 extern "C" {
 
+int wmf_debug_set_flags(int flags) { wmf_debug_flags = flags; return WMF_OK; }
 int wmf_profile_enable(int on) { g_prof_on = on != 0; return WMF_OK; }
 int wmf_profile_read(double* ms, int64_t* launches) {
     for (auto& r : g_prof) {

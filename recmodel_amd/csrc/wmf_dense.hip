@@ -26,12 +26,13 @@ __device__ __forceinline__ void gram_body(const float* __restrict__ Y, int64_t m
     for (int64_t s = step_lo; s < step_hi; ++s) {
         const int64_t row = 4 * s + q;
         const bool rok = row < m;
-        const float* yrow = Y + row * (int64_t)ld;
+        const float* yrow = Y + (rok ? row : 0) * (int64_t)ld;   // unconditional loads, masked afterwards
         float frag[NFB];
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) {
             const int col = 16 * fb + r;
-            float v = (rok && col < f) ? yrow[col] : 0.f;
+            float v = yrow[min(col, ld - 1)];
+            v = (rok && col < f) ? v : 0.f;
             if (bias && col == 0 && rok) v = 1.f;
             frag[fb] = v;
         }
@@ -134,6 +135,7 @@ int wmf_gram_nwaves(int64_t m) {
 
 int wmf_launch_gram(const float* Y, int64_t m, int f, int ld, int bias, double* G_sum, float* partial, double* slices,
                     hipStream_t st) {
+    if (m <= 0) return hipMemsetAsync(G_sum, 0, (size_t)f * f * sizeof(double), st) == hipSuccess ? 0 : -1;
     const int nfb = (f + 15) / 16;
     const int nwaves = wmf_gram_nwaves(m);
     WmfProfScope* ps = new WmfProfScope(WMF_SLOT_GRAM, st);
@@ -288,19 +290,19 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
     for (int64_t blk = (int64_t)blockIdx.x * 8 + wv; blk < nblocks16; blk += (int64_t)gridDim.x * 8) {
         const int64_t row = blk * 16 + r;
         const bool rok = row < m;
-        const float4* irow = reinterpret_cast<const float4*>(in + row * (int64_t)ld);
+        const float4* irow = reinterpret_cast<const float4*>(in + (rok ? row : 0) * (int64_t)ld);   // loads are unconditional
         f32x4 acc[NFB];
 #pragma unroll
         for (int nb = 0; nb < NFB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rok && q < nch) xn = irow[q];
+        float4 xn = irow[min(q, nch - 1)];
+        if (!(rok && q < nch)) xn = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
         for (int t = 0; t < NFB; ++t) {
             const int c = 4 * t + q;                 // 16-byte piece index within the row
             const float4 x = xn;
             if (t + 1 < NFB) {                       // prefetch the next piece
-                xn = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rok && c + 4 < nch) xn = irow[c + 4];
+                xn = irow[min(c + 4, nch - 1)];
+                if (!(rok && c + 4 < nch)) xn = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             const int k0 = 4 * c;
             float xe[4] = {x.x, x.y, x.z, x.w};

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, (NFB <= 4 ? 4 : (NFB <= 6 ? 2 : 1))) void solv
                                                            const int32_t* __restrict__ indices,
                                                            const float* __restrict__ vals, int f, int ld,
                                                            float* __restrict__ g, int32_t* __restrict__ fb_rows,
-                                                           int32_t* __restrict__ fb_count) {
+                                                           int32_t* __restrict__ fb_count, int dbg) {
     using C = DirectCfg<NFB>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
@@ -163,17 +163,18 @@ __global__ __launch_bounds__(256, (NFB <= 4 ? 4 : (NFB <= 6 ? 2 : 1))) void solv
     auto load_chunk = [&](float4 (&pre)[C::PF], float& wpre, int64_t lo, int d, int base) {
         const int nrow = min(C::RC, d - base);                   // may be <= 0: loads nothing
 #pragma unroll
-        for (int i = 0; i < C::PF; ++i) {
-            pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pj[i] < nrow) {
-                const int idx = indices[lo + base + pj[i]];
-                pre[i] = reinterpret_cast<const float4*>(V + (int64_t)idx * ld)[pc[i]];
-            }
+        for (int i = 0; i < C::PF; ++i) {                        // unconditional loads, masked afterwards
+            const bool on = pj[i] < nrow;
+            const int idx = indices[on ? lo + base + pj[i] : 0];
+            const float4 v = reinterpret_cast<const float4*>(V + (int64_t)idx * ld)[pc[i]];
+            pre[i] = on ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        wpre = 0.f;
-        if (tid < nrow) {
-            wpre = vals[lo + base + tid];
-            if (biasv) wpre -= biasv[indices[lo + base + tid]];
+        {
+            const bool on = tid < nrow;
+            const int64_t e = on ? lo + base + tid : 0;
+            float wv = vals[e];
+            if (biasv) wv -= biasv[indices[e]];
+            wpre = on ? wv : 0.f;
         }
     };
     for (int e = tid; e < C::RC * C::LDV; e += 256) Vs[e] = 0.f;       // pad columns [ld, LDV) stay zero for good
@@ -213,14 +214,14 @@ __global__ __launch_bounds__(256, (NFB <= 4 ? 4 : (NFB <= 6 ? 2 : 1))) void solv
             __syncthreads();
             if (c + 2 < nchunks) load_chunk(pre, wpre, lo, d, base + 2 * C::RC);
             else if (itn < count) load_chunk(pre, wpre, lon, dn, slot * C::RC);
-            const int nsteps = (nrow + 3) >> 2;
+            const int nsteps = (dbg & 2) ? 0 : (nrow + 3) >> 2;
             switch (wave) {
                 case 0: direct_chunk<NFB, 0>(Vs, wsm, nsteps, acc, r, q); break;
                 case 1: direct_chunk<NFB, 1>(Vs, wsm, nsteps, acc, r, q); break;
                 case 2: direct_chunk<NFB, 2>(Vs, wsm, nsteps, acc, r, q); break;
                 default: direct_chunk<NFB, 3>(Vs, wsm, nsteps, acc, r, q); break;
             }
-            if (tid < C::FP) {
+            if (tid < C::FP && !(dbg & 4)) {
                 float s = 0.f;
                 for (int j = 0; j < nrow; ++j) s += psm[j] * Vs[j * C::LDV + tid];
                 racc += s;
@@ -250,8 +251,8 @@ __global__ __launch_bounds__(256, (NFB <= 4 ? 4 : (NFB <= 6 ? 2 : 1))) void solv
         __syncthreads();
 
         // ---- C: blocked Cholesky of the leading NB blocks; block row NFB (the rhs) rides along
-        for (int kb = 0; kb < NB; ++kb) {
-            if (wave == 0) {
+        for (int kb = 0; kb < ((dbg & 1) ? 0 : NB); ++kb) {
+            if (wave == 0 && !(dbg & 8)) {
                 const bool ok = direct_diag<C::LDB>(Bm, T, kb, lane);
                 if (!ok && lane == 0) flag[0] = 1;
             }
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256, (NFB <= 4 ? 4 : (NFB <= 6 ? 2 : 1))) void solv
         const bool notpd = flag[0] != 0;
         if (notpd && tid == 0) fb_rows[atomicAdd(fb_count, 1)] = u;   // not positive definite: the LU kernel redoes it
         // ---- D: back substitution  g = L^-T y,  y = row FP of Bm.  Wave 0, lane (c = r, part = q).
-        if (wave == 0 && !notpd) {
+        if (wave == 0 && !notpd && !(dbg & 1)) {
             for (int kb = NB - 1; kb >= 0; --kb) {
                 float z = 0.f;
                 for (int i = 16 * (kb + 1) + q; i < 16 * NB; i += 4) z += Bm[i * C::LDB + 16 * kb + r] * gs[i];
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256, (NFB <= 4 ? 4 : (NFB <= 6 ? 2 : 1))) void solv
 template <int NFB>
 static void launch_direct_nfb(const int32_t* rows, int64_t count, const float* V, const float* biasv,
                               const int64_t* indptr, const int32_t* indices, const float* vals, int f, int ld, float* g,
-                              int32_t* fb_rows, int32_t* fb_count, hipStream_t st) {
+                              int32_t* fb_rows, int32_t* fb_count, int dbg, hipStream_t st) {
     using C = DirectCfg<NFB>;
     constexpr size_t lds = (size_t)C::TOTAL * 4;
     static bool attr_set = false;
@@ -340,7 +341,7 @@ static void launch_direct_nfb(const int32_t* rows, int64_t count, const float* V
     int64_t grid = 256 * (int64_t)(per_cu > 8 ? 8 : per_cu) * 2;
     if (grid > count) grid = count;
     hipLaunchKernelGGL((solve_direct_kernel<NFB>), dim3((unsigned)grid), dim3(256), lds, st, rows, count, V, biasv, indptr,
-                       indices, vals, f, ld, g, fb_rows, fb_count);
+                       indices, vals, f, ld, g, fb_rows, fb_count, dbg);
 }
 
 int wmf_direct_supported(int f) { return f >= 1 && f <= 144; }
@@ -349,8 +350,9 @@ int wmf_launch_direct(const int32_t* rows, int64_t count, const float* V, const 
                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
                       int32_t* fb_count, hipStream_t st) {
     if (count <= 0) return 0;
+    const int dbg = wmf_debug_flags;
     switch ((f + 15) / 16) {
-#define C_(N) case N: launch_direct_nfb<N>(rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, st); break;
+#define C_(N) case N: launch_direct_nfb<N>(rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, st); break;
         C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9)
 #undef C_
         default: return -1;

@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256) void eval_kernel(const float* __restrict__ use
         for (int64_t jb = lo; jb < hi; jb += 4) {                  // uniform trip count across the 4 groups
             const int64_t j = jb + grp;
             const bool act = j < hi;
-            const float v = act ? vals[j] : 0.f;
-            const int i = act ? indices[j] : 0;
+            const int64_t e = act ? j : lo;                       // lo < hi inside this loop: a valid entry
+            const float v = vals[e];
+            const int i = indices[e];
             const float s = pair_score(xu, items + (int64_t)i * ld, nch, gl, bias);
             if (act && gl == 0 && v != 0.f) {
                 const double e = (double)v - (double)s;

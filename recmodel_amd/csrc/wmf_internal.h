@@ -35,6 +35,9 @@ int wmf_direct_supported(int f);
 int wmf_launch_direct(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
                       int32_t* fb_count, hipStream_t st);
+int wmf_launch_direct64(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
+                        const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
+                        int32_t* fb_count, hipStream_t st);
 int wmf_launch_spmm(const float* V, const int64_t* indptr, const int32_t* indices, const float* values, int64_t n,
                     int ld, float* g, hipStream_t st);
 int wmf_launch_eval(const float* users, const float* items, int f, int ld, int bias, const int64_t* indptr,
@@ -45,6 +48,7 @@ int wmf_launch_predict(const float* users, const float* items, int f, int ld, in
 int wmf_launch_confidence(float* values, int64_t nnz, double alpha, double beta, int mode, hipStream_t st);
 
 void wmf_set_error(const char* fmt, ...);
+extern int wmf_debug_flags;   // timing experiments only (tools/kernel_lab.py); 0 in normal use
 
 // per-kernel event timing (wmf_api.hip)
 enum {

@@ -79,28 +79,33 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
     const int r = lane & 15, q = lane >> 4;
     const int nch = ld >> 2;
 
+    // All loads are unconditional (clamped to a stored entry) and their values are MULTIPLIED by a
+    // 0/1 mask: under a per-lane select hipcc sinks the load into a branch and waits for each in turn.
     float w[NSETS], p[NSETS];
     float4 x[NSETS][NCH];
     bool neg = false;
+    const float4* Vq = reinterpret_cast<const float4*>(V) + q;      // this lane's pieces are q, q+4, q+8, ...
+    const int last_c = min(4 * (NCH - 1) + q, nch - 1);
+    const float last_m = (4 * (NCH - 1) + q < nch) ? 1.f : 0.f;
 #pragma unroll
     for (int s = 0; s < NSETS; ++s) {
         const int j = r + 16 * s;
-        const bool act = j < d;
-        int idx = 0;
-        float wj = 0.f;
-        if (act) {
-            idx = indices[lo + j];
-            wj = vals[lo + j];
-            if (biasv) wj -= biasv[idx];
-            if (!(wj >= 0.f)) neg = true;           // negative or NaN weight: needs pivoting
-        }
+        const float am = j < d ? 1.f : 0.f;
+        const int64_t e = j < d ? lo + j : 0;       // entry 0 exists: the launcher skips matrices without entries
+        const int idx = indices[e];
+        float wj = vals[e];
+        if (biasv) wj -= biasv[idx];
+        wj *= am;
+        if (!(wj >= 0.f)) neg = true;               // negative or NaN weight: needs pivoting
         w[s] = wj;
         p[s] = wj + 1.f;
-        const float4* vrow = reinterpret_cast<const float4*>(V + (int64_t)idx * ld);
+        const float4* vrow = Vq + (int64_t)idx * nch;
 #pragma unroll
         for (int t = 0; t < NCH; ++t) {
-            const int c = 4 * t + q;
-            x[s][t] = (act && c < nch) ? vrow[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            // only the last piece index can run past the row (nch > 4 (NCH - 1) by construction)
+            const float4 v = (t < NCH - 1) ? vrow[4 * t] : (vrow - q)[last_c];
+            const float m = (t < NCH - 1) ? am : am * last_m;
+            x[s][t] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
         }
     }
     if (__any(neg)) {                               // wave-uniform: bounce the row to the LU kernel
@@ -369,6 +374,8 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
                      const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fail_count,
                      hipStream_t st) {
     if (hipMemsetAsync(pl->fallback_count, 0, sizeof(int32_t), st) != hipSuccess) return -2;
+    if (pl->nnz[0] + pl->nnz[1] + pl->nnz[2] + pl->nnz[3] == 0)      // nothing stored: every row solves to zero
+        return hipMemsetAsync(g, 0, (size_t)pl->n * ld * sizeof(float), st) == hipSuccess ? 0 : -2;
     switch ((ld + 15) / 16) {
 #define C(N) case N: launch_low<N>(pl, V, biasv, indptr, indices, vals, ld, g, st); break;
         C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)
@@ -378,8 +385,10 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
     const bool general_ok = f <= 144;
     if (pl->count[WMF_BIN_MFMA] > 0) {
         WmfProfScope ps(WMF_SLOT_SOLVE_DIRECT, st);
-        if (wmf_launch_direct(pl->rows[WMF_BIN_MFMA], pl->count[WMF_BIN_MFMA], V, biasv, indptr, indices, vals, f, ld, g,
-                              pl->fallback_rows, pl->fallback_count, st)) return -1;
+        const bool one_wave = f <= 64 && !(wmf_debug_flags & 16);
+        if ((one_wave ? wmf_launch_direct64 : wmf_launch_direct)(pl->rows[WMF_BIN_MFMA], pl->count[WMF_BIN_MFMA], V, biasv,
+                                                                 indptr, indices, vals, f, ld, g, pl->fallback_rows,
+                                                                 pl->fallback_count, st)) return -1;
     }
     if (pl->count[WMF_BIN_GENERAL] > 0) {
         if (!general_ok) return -1;
