@@ -43,30 +43,29 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg_name, counts_csr, k, bias, gamma, n_items, sample_users):
+def cpu_baseline(cfg_name, user_rows, item_rows, users_f, k, bias, gamma, n_items):
     """The oracle's NumPy restatement of recompute_factors[_bias] (same per-row gather / dot / solve
-    structure as RecModel/wmf_model.py:220-239, one thread) on a row sample of the same matrix."""
+    structure as RecModel/wmf_model.py:220-239, one thread) on row samples of the same matrices:
+    ``user_rows`` = the first rows of the user-major count matrix, ``item_rows`` = the first rows of
+    the item-major confidence matrix (full degree), in the job's users:items row ratio."""
     from oracle import wmf_oracle as orc
     from threadpoolctl import threadpool_limits
     with threadpool_limits(limits=1):
-        C = counts_csr[:sample_users].astype(np.float64)
+        C = user_rows.astype(np.float64)
         C.data = orc.confidence_transform(C.data)
         items = orc.init_items(n_items, k, bias)
         step = orc.recompute_factors_bias if bias else orc.recompute_factors
         t0 = time.perf_counter()
-        users = step(items, C, gamma)
+        step(items, C, gamma)
         t_u = time.perf_counter() - t0
-        # item half on the same user sample, with a 1:10 share of item rows as in the full job
-        CT = C.T.tocsr()
-        sample_items = max(1, sample_users // 10)
-        CT = CT[:sample_items]
+        CT = item_rows.astype(np.float64)
         t0 = time.perf_counter()
-        step(users, CT, gamma)
+        step(users_f, CT, gamma)
         t_i = time.perf_counter() - t0
-    rows = sample_users + sample_items
+    rows = C.shape[0] + CT.shape[0]
     return {"value": rows / (t_u + t_i), "unit": "row-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{cfg_name}: first {sample_users} user rows ({C.nnz} nnz, {t_u:.1f}s) + first {sample_items} "
-                      f"item rows of their transpose ({CT.nnz} nnz, {t_i:.1f}s), NumPy per-row loop, 1 BLAS thread",
+            "sample": f"{cfg_name}: first {C.shape[0]} user rows ({C.nnz} nnz, {t_u:.1f}s) + first {CT.shape[0]} item rows "
+                      f"({CT.nnz} nnz, {t_i:.1f}s) of the same matrix, NumPy per-row loop, 1 BLAS thread",
             "host_cpus": os.cpu_count()}
 
 
@@ -104,8 +103,7 @@ def main():
     nnz = int(indices.numel())
     eng = AlsEngine(n_users, n_items, k, bias, gamma, device=dev)
     values = counts.clone()
-    _lib.check(lib.wmf_confidence_transform(ctypes.c_void_p(values.data_ptr()), nnz, 10.0, 1.0, 0,
-                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    eng.K.confidence_transform(values, 10.0, 1.0, 0)
     eng.set_interactions(indptr, indices, values)
     from oracle import wmf_oracle as orc            # init only: the legacy-RNG draw of wmf_model.py:10-17
     eng.set_factors("items", orc.init_items(n_items, k, bias))
@@ -207,11 +205,20 @@ def main():
         "row_bins": {s: {"rows": eng.csr[s].bin_rows.tolist(), "nnz": eng.csr[s].bin_nnz.tolist()} for s in ("users", "items")},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sample = args.cpu_users or {64: 100_000, 128: 30_000, 16: 943}.get(k, 20_000)
-        sample = min(sample, n_users_1)
-        ip = indptr[: sample + 1].cpu().numpy()
-        mat = synth.to_scipy(indptr[: sample + 1], indices[: ip[-1]], counts[: ip[-1]], (sample, n_items))
-        out["cpu_baseline"] = cpu_baseline(args.config, mat, k, bias, gamma, n_items, sample)
+        su = args.cpu_users or {64: 100_000, 128: 30_000, 16: 943}.get(k, 20_000)
+        su = min(su, n_users_1)
+        si = max(1, min(n_items, su * n_items // n_users_1))
+        ip = indptr[: su + 1].cpu().numpy()
+        user_rows = synth.to_scipy(indptr[: su + 1], indices[: ip[-1]], counts[: ip[-1]], (su, n_items))
+        ci = eng.csr["items"]                                    # item-major confidence matrix (world == 1: positions = ids)
+        ipi = ci.indptr[: si + 1].cpu().numpy()
+        item_rows = synth.to_scipy(ci.indptr[: si + 1], ci.indices[: ipi[-1]].to(torch.int64), ci.values[: ipi[-1]],
+                                   (si, n_users))
+        if n_users <= 2_000_000:
+            users_f = eng.get_factors("users")
+        else:                                                    # timing does not depend on the values
+            users_f = np.random.default_rng(0).random((n_users, eng.f), dtype=np.float32)
+        out["cpu_baseline"] = cpu_baseline(args.config, user_rows, item_rows, users_f, k, bias, gamma, n_items)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -1,8 +1,9 @@
 """Device-resident WMF/ALS engine: the host side of the hot path above the C ABI.
 
 One ``AlsEngine`` per process and per GPU.  Everything numerical is a call into libwmf_hip.so
-(``include/wmf_hip.h``); torch supplies device memory, the HIP stream and -- for more than one
-GPU -- ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI).  There is no CPU code path.
+(``include/wmf_hip.h``) through ``HipKernels``; torch supplies device memory, the HIP stream and --
+for more than one GPU -- ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI).  The package
+has no CPU compute path: constructing an engine without a GPU raises.
 
 Restates the control structure of ``WMF.train``'s weighted branch (RecModel/wmf_model.py:134-161):
 
@@ -33,11 +34,67 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class HipKernels:
+    """The compute backend: every method is one entry point of libwmf_hip.so (include/wmf_hip.h) on
+    torch-owned device buffers and torch's current HIP stream.  This is the only backend the package
+    ships; the class exists so the host logic above it (sharding, collectives, control flow) can be
+    exercised on CPU ranks in tests with a stand-in that has the same methods."""
+
+    def __init__(self):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+
+    def ld_for(self, f):
+        return int(self.lib.wmf_ld_for(f))
+
+    def gram_workspace_bytes(self, f):
+        return int(self.lib.wmf_gram_workspace_bytes(f))
+
+    def eval_workspace_bytes(self):
+        return int(self.lib.wmf_eval_workspace_bytes())
+
+    def gram(self, Y, m, f, ld, bias, G, ws):
+        _lib.check(self.lib.wmf_gram(_ptr(Y), m, f, ld, int(bias), _ptr(G), _ptr(ws), _stream()))
+
+    def factorize(self, G, f, ld, lam, W_white, W_unwhite, info, ws):
+        _lib.check(self.lib.wmf_factorize(_ptr(G), f, ld, float(lam), _ptr(W_white), _ptr(W_unwhite), _ptr(info), _ptr(ws),
+                                          _stream()))
+
+    def row_transform(self, inp, m, f, ld, W, set_col0_one, out, col0_out):
+        _lib.check(self.lib.wmf_row_transform(_ptr(inp), m, f, ld, _ptr(W), int(set_col0_one), _ptr(out), _ptr(col0_out),
+                                              _stream()))
+
+    def plan_create(self, indptr_host, n, f):
+        handle = ctypes.c_void_p()
+        _lib.check(self.lib.wmf_plan_create(indptr_host.ctypes.data_as(ctypes.c_void_p), n, f, ctypes.byref(handle)))
+        stats = np.zeros(8, dtype=np.int64)
+        _lib.check(self.lib.wmf_plan_stats(handle, stats.ctypes.data_as(ctypes.c_void_p)))
+        return handle, stats
+
+    def plan_destroy(self, handle):
+        self.lib.wmf_plan_destroy(handle)
+
+    def solve_rows(self, plan, V, bias_vec, indptr, indices, values, n, f, ld, g, fail):
+        _lib.check(self.lib.wmf_solve_rows(plan, _ptr(V), _ptr(bias_vec), _ptr(indptr), _ptr(indices), _ptr(values), n, f, ld,
+                                           _ptr(g), _ptr(fail), _stream()))
+
+    def spmm_rows(self, V, indptr, indices, values, n, f, ld, g):
+        _lib.check(self.lib.wmf_spmm_rows(_ptr(V), _ptr(indptr), _ptr(indices), _ptr(values), n, f, ld, _ptr(g), _stream()))
+
+    def eval_sqerr(self, users, items, f, ld, bias, indptr, indices, values, n, out3, ws):
+        _lib.check(self.lib.wmf_eval_sqerr(_ptr(users), _ptr(items), f, ld, int(bias), _ptr(indptr), _ptr(indices),
+                                           _ptr(values), n, _ptr(out3), _ptr(ws), _stream()))
+
+    def confidence_transform(self, values, alpha, beta, mode):
+        _lib.check(self.lib.wmf_confidence_transform(_ptr(values), values.numel(), float(alpha), float(beta), int(mode),
+                                                     _stream()))
+
+
 class Csr:
     """CSR shard resident in HBM (int64 indptr, int32 indices, fp32 values) plus its row plan."""
 
-    def __init__(self, indptr, indices, values, n_cols, f):
-        lib = _lib.load()
+    def __init__(self, kernels, indptr, indices, values, n_cols, f):
+        self.kernels = kernels
         self.indptr = indptr.to(torch.int64).contiguous()
         self.indices = indices.to(torch.int32).contiguous()
         self.values = values.to(torch.float32).contiguous()
@@ -46,18 +103,14 @@ class Csr:
         self.nnz = int(self.indices.numel())
         self.f = f
         host_ptr = np.ascontiguousarray(self.indptr.cpu().numpy(), dtype=np.int64)
-        handle = ctypes.c_void_p()
-        _lib.check(lib.wmf_plan_create(host_ptr.ctypes.data_as(ctypes.c_void_p), self.n_rows, f, ctypes.byref(handle)))
-        self._plan = handle
-        stats = np.zeros(8, dtype=np.int64)
-        _lib.check(lib.wmf_plan_stats(self._plan, stats.ctypes.data_as(ctypes.c_void_p)))
+        self._plan, stats = kernels.plan_create(host_ptr, self.n_rows, f)
         self.bin_rows, self.bin_nnz = stats[:4].copy(), stats[4:].copy()
 
     def __del__(self):
         plan, self._plan = getattr(self, "_plan", None), None
         if plan:
             try:
-                _lib.load().wmf_plan_destroy(plan)
+                self.kernels.plan_destroy(plan)
             except Exception:
                 pass
 
@@ -77,9 +130,9 @@ def coo_to_csr(rows, cols, vals, n_rows):
 class AlsEngine:
     """Weighted-ALS state of one rank: factor blocks, whitened gathers, CSR shards."""
 
-    def __init__(self, n_users, n_items, dim, bias, gamma, device=None, group=None):
-        _lib.require_gpu()
-        self.lib = _lib.load()
+    def __init__(self, n_users, n_items, dim, bias, gamma, device=None, group=None, kernels=None):
+        self.K = kernels if kernels is not None else HipKernels()     # raises without a GPU / built library
+        self.lib = getattr(self.K, "lib", None)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.group = group
         if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -90,7 +143,7 @@ class AlsEngine:
         self.n = {"users": int(n_users), "items": int(n_items)}
         self.dim, self.bias, self.gamma = int(dim), bool(bias), float(gamma)
         self.f = self.dim + 1 if self.bias else self.dim
-        self.ld = int(self.lib.wmf_ld_for(self.f))
+        self.ld = self.K.ld_for(self.f)
         W = self.world
         self.rpr = {s: (self.n[s] + W - 1) // W for s in self.n}            # rows per rank (padded)
         self.n_local = {s: len(range(self.rank, self.n[s], W)) for s in self.n}
@@ -106,8 +159,8 @@ class AlsEngine:
         self.W_white, self.W_unwhite = z(self.f, self.ld), z(self.f, self.ld)
         self.info = z(4, dtype=torch.int32)
         self.fail = z(4, dtype=torch.int32)
-        self.ws = torch.empty(int(self.lib.wmf_gram_workspace_bytes(self.f)), dtype=torch.uint8, device=dev)
-        self.eval_ws = torch.empty(int(self.lib.wmf_eval_workspace_bytes()), dtype=torch.uint8, device=dev)
+        self.ws = torch.empty(self.K.gram_workspace_bytes(self.f), dtype=torch.uint8, device=dev)
+        self.eval_ws = torch.empty(self.K.eval_workspace_bytes(), dtype=torch.uint8, device=dev)
         self.eval_out = z(3, dtype=torch.float64)
         self.csr = {}          # "users": shard with local user rows, "items": shard with local item rows
         self.has_factors = {"users": False, "items": False}
@@ -142,7 +195,7 @@ class AlsEngine:
             rows, cols, vals = rows[mine], cols[mine], vals[mine]
         local = rows // W
         indptr, idx, v = coo_to_csr(local, self.positions(other, cols), vals, self.rpr[side])
-        return Csr(indptr, idx, v, W * self.rpr[other], self.f)
+        return Csr(self.K, indptr, idx, v, W * self.rpr[other], self.f)
 
     def set_factors(self, side, full):
         """Load a full host/device [n, f] factor matrix (reference layout) into this rank's block."""
@@ -168,20 +221,18 @@ class AlsEngine:
     def prepare(self, fixed):
         """Gramian of the fixed side, its Cholesky factor, and the gathered whitened factors.
         wmf_model.py:215 / :328-332."""
-        lib, st = self.lib, _stream()
+        K = self.K
         blk = self.factors[fixed]
-        _lib.check(lib.wmf_gram(_ptr(blk), self.n_local[fixed], self.f, self.ld, int(self.bias), _ptr(self.G),
-                                _ptr(self.ws), st))
+        K.gram(blk, self.n_local[fixed], self.f, self.ld, self.bias, self.G, self.ws)
         if self.world > 1:
             torch.distributed.all_reduce(self.G, group=self.group)
-        _lib.check(lib.wmf_factorize(_ptr(self.G), self.f, self.ld, self.gamma, _ptr(self.W_white),
-                                     _ptr(self.W_unwhite), _ptr(self.info), _ptr(self.ws), st))
+        K.factorize(self.G, self.f, self.ld, self.gamma, self.W_white, self.W_unwhite, self.info, self.ws)
         V, bvec = self.V[fixed], self.bias_vec[fixed]
         lo = self.rank * self.rpr[fixed]
         v_loc = V[lo: lo + self.rpr[fixed]]
         b_loc = bvec[lo: lo + self.rpr[fixed]]
-        _lib.check(lib.wmf_row_transform(_ptr(blk), self.n_local[fixed], self.f, self.ld, _ptr(self.W_white),
-                                         int(self.bias), _ptr(v_loc), _ptr(b_loc) if self.bias else None, st))
+        K.row_transform(blk, self.n_local[fixed], self.f, self.ld, self.W_white, self.bias, v_loc,
+                        b_loc if self.bias else None)
         if self.world > 1:
             torch.distributed.all_gather_into_tensor(V, v_loc, group=self.group)
             if self.bias:
@@ -189,14 +240,12 @@ class AlsEngine:
 
     def update(self, side):
         """Solve every local row of ``side`` against the prepared fixed side.  wmf_model.py:220-239."""
-        lib, st = self.lib, _stream()
+        K = self.K
         fixed = self._other(side)
         c = self.csr[side]
-        _lib.check(lib.wmf_solve_rows(c._plan, _ptr(self.V[fixed]), _ptr(self.bias_vec[fixed]) if self.bias else None,
-                                      _ptr(c.indptr), _ptr(c.indices), _ptr(c.values), c.n_rows, self.f, self.ld,
-                                      _ptr(self.g[side]), _ptr(self.fail), st))
-        _lib.check(lib.wmf_row_transform(_ptr(self.g[side]), self.n_local[side], self.f, self.ld,
-                                         _ptr(self.W_unwhite), 0, _ptr(self.factors[side]), None, st))
+        K.solve_rows(c._plan, self.V[fixed], self.bias_vec[fixed] if self.bias else None, c.indptr, c.indices, c.values,
+                     c.n_rows, self.f, self.ld, self.g[side], self.fail)
+        K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, False, self.factors[side], None)
         self.has_factors[side] = True
 
     def half_step(self, side):
@@ -207,14 +256,12 @@ class AlsEngine:
     def half_step_unweighted(self, side):
         """Closed form of the un-weighted branch, wmf_model.py:85,88:
         side = R . Y . (Y^T Y + gamma I)^-1  =  (R . V) . L^-1  with V = Y L^-T."""
-        lib, st = self.lib, _stream()
+        K = self.K
         fixed = self._other(side)
         self.prepare(fixed)
         c = self.csr[side]
-        _lib.check(lib.wmf_spmm_rows(_ptr(self.V[fixed]), _ptr(c.indptr), _ptr(c.indices), _ptr(c.values), c.n_rows,
-                                     self.f, self.ld, _ptr(self.g[side]), st))
-        _lib.check(lib.wmf_row_transform(_ptr(self.g[side]), self.n_local[side], self.f, self.ld,
-                                         _ptr(self.W_unwhite), 0, _ptr(self.factors[side]), None, st))
+        K.spmm_rows(self.V[fixed], c.indptr, c.indices, c.values, c.n_rows, self.f, self.ld, self.g[side])
+        K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, False, self.factors[side], None)
         self.has_factors[side] = True
 
     def check_numerics(self):
@@ -238,15 +285,13 @@ class AlsEngine:
     def eval_sums(self, shard):
         """(sum of squared errors, sum of absolute errors, count) over the stored non-zero entries
         of ``shard``; all-reduced over ranks.  base_model.py:163-176."""
-        lib, st = self.lib, _stream()
         items = self.factors["items"]
         if self.world > 1:
             full = torch.empty(self.world * self.rpr["items"], self.ld, dtype=torch.float32, device=self.device)
             torch.distributed.all_gather_into_tensor(full, items, group=self.group)
             items = full
-        _lib.check(lib.wmf_eval_sqerr(_ptr(self.factors["users"]), _ptr(items), self.f, self.ld, int(self.bias),
-                                      _ptr(shard.indptr), _ptr(shard.indices), _ptr(shard.values), shard.n_rows,
-                                      _ptr(self.eval_out), _ptr(self.eval_ws), st))
+        self.K.eval_sqerr(self.factors["users"], items, self.f, self.ld, self.bias, shard.indptr, shard.indices,
+                          shard.values, shard.n_rows, self.eval_out, self.eval_ws)
         if self.world > 1:
             torch.distributed.all_reduce(self.eval_out, group=self.group)
         return tuple(float(x) for x in self.eval_out.cpu())

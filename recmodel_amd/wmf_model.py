@@ -215,9 +215,8 @@ class WMF(RecModel):
         if self.bias is not True and self.bias is not False:
             raise ValueError(f"self.bias = {self.bias} is unknown. Only True / False are allowed.")
         indptr, indices, values = _csr_parts(count_mat)
-        values = values.cuda()
-        _lib.check(eng.lib.wmf_confidence_transform(_ptr(values), values.numel(), float(alpha), float(beta),
-                                                    0 if pre_process_count == 'log' else 1, _stream()))
+        values = values.to(eng.device)
+        eng.K.confidence_transform(values, alpha, beta, 0 if pre_process_count == 'log' else 1)
         eng.set_interactions(indptr, indices, values)      # also builds the item-major shard (:128)
         eval_shard = self._train_eval_shard(eng, eval_mat)
         train_shard = eng.make_eval_shard(*_csr_parts(utility_mat)) if verbose > 1 else None

@@ -1,0 +1,93 @@
+"""CPU stand-in for recmodel_amd.engine.HipKernels -- TEST INFRASTRUCTURE ONLY.
+
+Same method surface, NumPy arithmetic on CPU torch tensors, so that the host logic of AlsEngine
+(round-robin sharding, position maps, the Gramian all-reduce and the all-gather of the whitened
+block, padding rows, eval reduction) can run on gloo ranks without a GPU.  It is never imported by
+the package; the HIP kernels themselves are tested on the GPU (tests/test_gpu_parity.py)."""
+import numpy as np
+
+
+class NumpyKernels:
+    def ld_for(self, f):
+        return (f + 3) & ~3
+
+    def gram_workspace_bytes(self, f):
+        return 16
+
+    def eval_workspace_bytes(self):
+        return 16
+
+    def gram(self, Y, m, f, ld, bias, G, ws):
+        y = Y.numpy()[:m, :f].astype(np.float64).copy()
+        if bias:
+            y[:, 0] = 1.0
+        G.numpy()[:] = (y.T @ y).reshape(-1)
+
+    def factorize(self, G, f, ld, lam, W_white, W_unwhite, info, ws):
+        A = G.numpy().reshape(f, f) + lam * np.eye(f)
+        Linv = np.linalg.inv(np.linalg.cholesky(A))
+        W_white.numpy()[:] = 0
+        W_unwhite.numpy()[:] = 0
+        W_white.numpy()[:, :f] = Linv.T
+        W_unwhite.numpy()[:, :f] = Linv
+        info.numpy()[0] = 0
+
+    def row_transform(self, inp, m, f, ld, W, set_col0_one, out, col0_out):
+        x = inp.numpy()[:m, :f].astype(np.float64).copy()
+        if set_col0_one:
+            if col0_out is not None:
+                col0_out.numpy()[:m] = inp.numpy()[:m, 0]
+            x[:, 0] = 1.0
+        o = out.numpy()
+        o[:m] = 0
+        o[:m, :f] = x @ W.numpy()[:, :f].astype(np.float64)
+
+    def plan_create(self, indptr_host, n, f):
+        deg = np.diff(indptr_host)
+        stats = np.zeros(8, dtype=np.int64)
+        stats[0], stats[4] = n, deg.sum()
+        return ("plan", n, f), stats
+
+    def plan_destroy(self, handle):
+        pass
+
+    def solve_rows(self, plan, V, bias_vec, indptr, indices, values, n, f, ld, g, fail):
+        v = V.numpy().astype(np.float64)
+        ip, ix, w = indptr.numpy(), indices.numpy(), values.numpy().astype(np.float64)
+        b = bias_vec.numpy().astype(np.float64) if bias_vec is not None else None
+        out = g.numpy()
+        out[:n] = 0
+        for u in range(n):
+            lo, hi = ip[u], ip[u + 1]
+            if hi == lo:
+                continue
+            idx = ix[lo:hi]
+            wu = w[lo:hi] - (b[idx] if b is not None else 0.0)
+            vu = v[idx, :f]
+            out[u, :f] = np.linalg.solve(np.eye(f) + vu.T @ (vu * wu[:, None]), (wu + 1.0) @ vu)
+
+    def spmm_rows(self, V, indptr, indices, values, n, f, ld, g):
+        v = V.numpy().astype(np.float64)
+        ip, ix, w = indptr.numpy(), indices.numpy(), values.numpy().astype(np.float64)
+        out = g.numpy()
+        out[:n] = 0
+        for u in range(n):
+            lo, hi = ip[u], ip[u + 1]
+            out[u, :f] = w[lo:hi] @ v[ix[lo:hi], :f]
+
+    def eval_sqerr(self, users, items, f, ld, bias, indptr, indices, values, n, out3, ws):
+        x, y = users.numpy().astype(np.float64), items.numpy().astype(np.float64)
+        ip, ix, val = indptr.numpy(), indices.numpy(), values.numpy().astype(np.float64)
+        rows = np.repeat(np.arange(n), np.diff(ip))
+        keep = val != 0
+        rows, cols, val = rows[keep], ix[keep], val[keep]
+        if bias:
+            pred = (x[rows, 1:f] * y[cols, 1:f]).sum(1) + x[rows, 0] + y[cols, 0]
+        else:
+            pred = (x[rows, :f] * y[cols, :f]).sum(1)
+        e = val - pred
+        out3.numpy()[:] = [np.sum(e * e), np.sum(np.abs(e)), float(len(e))]
+
+    def confidence_transform(self, values, alpha, beta, mode):
+        v = values.numpy()
+        v[:] = alpha * np.log(1 + beta * v) if mode == 0 else alpha * v

@@ -1,0 +1,102 @@
+"""world_size-2 gloo test of the multi-rank host path on CPU.
+
+Each rank runs AlsEngine with the NumPy stand-in backend: users and items dealt round-robin, one
+all-reduce of the f x f Gramian and one all-gather of the whitened block per half step, factors
+gathered back in id order.  The result must equal the single-process oracle on the full matrix."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, bias, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_kernels import NumpyKernels
+        from oracle import wmf_oracle as orc
+        from recmodel_amd import synth
+        from recmodel_amd.engine import AlsEngine
+        n_users, n_items, dim = 203, 57, 6           # not multiples of the world size: padding rows exist
+        indptr, indices, counts = synth.make_counts(n_users, n_items, 5, seed=11)
+        values = (10 * torch.log(1 + counts)).to(torch.float32)
+        eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cpu", kernels=NumpyKernels())
+        assert eng.world == world and eng.rank == rank
+        eng.set_interactions(indptr, indices, values)
+        # every stored entry lands on exactly one rank, in both orientations
+        for side in ("users", "items"):
+            t = torch.tensor([eng.csr[side].nnz], dtype=torch.int64)
+            dist.all_reduce(t)
+            assert int(t) == indices.numel()
+        eng.set_factors("items", orc.init_items(n_items, dim, bias))
+        for _ in range(2):
+            eng.half_step("users")
+            eng.half_step("items")
+        eng.check_numerics()
+        shard = eng.make_eval_shard(indptr, indices, counts)
+        sq, ab, cnt = eng.eval_sums(shard)
+        users, items = eng.get_factors("users"), eng.get_factors("items")
+        if rank == 0:
+            np.savez(out_path, users=users, items=items, sums=np.array([sq, ab, cnt]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_two_rank_als_matches_single_process_oracle(tmp_path, bias):
+    from oracle import wmf_oracle as orc
+    from recmodel_amd import synth
+    out = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(2, _free_port(), bias, out), nprocs=2, join=True)
+    got = np.load(out)
+    n_users, n_items, dim = 203, 57, 6
+    indptr, indices, counts = synth.make_counts(n_users, n_items, 5, seed=11)
+    raw = synth.to_scipy(indptr, indices, counts, (n_users, n_items))
+    C = raw.astype(np.float64)
+    C.data = 10 * np.log(1 + C.data)
+    CT = C.T.tocsr()
+    items = orc.init_items(n_items, dim, bias)
+    step = orc.recompute_factors_bias if bias else orc.recompute_factors
+    for _ in range(2):
+        users = step(items, C, 0.1)
+        items = step(users, CT, 0.1)
+    np.testing.assert_allclose(got["users"], users, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(got["items"], items, rtol=2e-4, atol=2e-5)
+    mse = orc.eval_prec(users, items, raw, bias)
+    assert abs(got["sums"][0] / got["sums"][2] - mse) <= 1e-4 * mse
+    assert got["sums"][2] == raw.nnz
+
+
+def test_single_rank_engine_with_stand_in_matches_oracle():
+    """world = 1 through the same code path (no process group)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fake_kernels import NumpyKernels
+    from oracle import wmf_oracle as orc
+    from recmodel_amd import synth
+    from recmodel_amd.engine import AlsEngine
+    n_users, n_items, dim = 90, 40, 5
+    indptr, indices, counts = synth.make_counts(n_users, n_items, 4, seed=3)
+    values = (10 * torch.log(1 + counts)).to(torch.float32)
+    eng = AlsEngine(n_users, n_items, dim, False, 0.1, device="cpu", kernels=NumpyKernels())
+    eng.set_interactions(indptr, indices, values)
+    eng.set_factors("items", orc.init_items(n_items, dim))
+    eng.half_step("users")
+    C = synth.to_scipy(indptr, indices, values, (n_users, n_items)).astype(np.float64)
+    want = orc.recompute_factors(orc.init_items(n_items, dim), C, 0.1)
+    np.testing.assert_allclose(eng.get_factors("users"), want, rtol=2e-4, atol=2e-5)
+    assert eng.algorithmic_bytes_half("users") == C.nnz * (4 * 5 + 8) + n_users * (4 * 5 + 4) + 4 * 25 + 4 * n_items * 5

@@ -102,3 +102,23 @@ def test_unweighted_branch():
 def test_bad_confidence_mode_raises():
     with pytest.raises(ValueError):
         orc.confidence_transform(np.ones(3), mode="sqrt")
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_c_restatement_matches_reference_golden(bias):
+    """oracle/wmf_oracle.c (double precision, own LU) against the reference's float64-count vectors."""
+    import subprocess
+    from conftest import ROOT
+    subprocess.check_call(["make", "-s", "-C", f"{ROOT}/oracle"])
+    from oracle import c_oracle
+    g = load_golden(f"half_bias{int(bias)}_float64.npz")
+    C, CT = csr_from(g, "C"), csr_from(g, "CT")
+    # the reference forms its Gramian in float32 (wmf_model.py:215); with biases the initial Gramian is
+    # ill conditioned (cond ~ 1e4) and that float32 rounding alone moves the reference by ~1e-5
+    rtol, atol = (1e-4, 3e-5) if bias else (2e-5, 2e-6)
+    np.testing.assert_allclose(c_oracle.half_step(g["items0"], C, 0.1, bias), g["users1"], rtol=rtol, atol=atol)
+    np.testing.assert_allclose(c_oracle.half_step(g["users1"], CT, 0.1, bias), g["items1"], rtol=rtol, atol=atol)
+    # and against the NumPy oracle (which, like the reference, forms the Gramian in float32: wmf_model.py:215)
+    step = orc.recompute_factors_bias if bias else orc.recompute_factors
+    np.testing.assert_allclose(c_oracle.half_step(g["items0"], C, 0.1, bias), step(g["items0"], C, 0.1, out_dtype="float64"),
+                               rtol=rtol, atol=max(atol, 5e-6))
