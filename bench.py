@@ -69,6 +69,24 @@ def cpu_baseline(cfg_name, user_rows, item_rows, users_f, k, bias, gamma, n_item
             "host_cpus": os.cpu_count()}
 
 
+def measured_traffic(config, slot, f, ld):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC profile of this
+    workload (profiles/rNN_<config>_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
+    this same command, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent."""
+    import glob
+    nfb, nch = (f + 15) // 16, (ld + 15) // 16
+    key = {0: f"gram_kernel<{nfb}, 1>", 3: f"transform_kernel<{nfb}, true>", 4: f"solve_low_kernel<{nch}, 1>",
+           5: f"solve_low_kernel<{nch}, 2>",
+           11: f"solve_direct64_kernel<{nfb}>" if f <= 64 else f"solve_direct_kernel<{nfb}>"}.get(slot)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config}_traffic.json")))
+    if not key or not files:
+        return None
+    k = json.load(open(files[-1])).get("kernels", {}).get(key)
+    if not k or k.get("FETCH_SIZE_KB_mean") is None:
+        return None
+    return (2.0 * k["FETCH_SIZE_KB_mean"] + k.get("WRITE_SIZE_KB_mean", 0.0)) * 1024.0
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,9 +194,10 @@ def main():
         per_launch = units_per_step * args.steps / launches[dom]
         avg_s = ms[dom] / launches[dom] / 1e3
         peak, unit, scale = (HBM_PEAK_GBS, "GB/s", 1e9) if bound == "hbm" else (F32_MFMA_PEAK_TF, "TFLOP/s", 1e12)
+        traffic = measured_traffic(args.config, dom, f, eng.ld)
         roofline = {"kernel": lib.wmf_profile_slot_name(dom).decode(), "bound": bound,
                     "achieved": per_launch / avg_s / scale, "peak": peak, "unit": unit,
-                    "frac": per_launch / avg_s / scale / peak, "traffic": None,
+                    "frac": per_launch / avg_s / scale / peak, "traffic": traffic,
                     "algorithmic_units_per_launch": per_launch, "avg_launch_ms": avg_s * 1e3,
                     "share_of_step": float(ms[dom] / (elapsed * 1e3))}
     epoch_bytes = sum(eng.algorithmic_bytes_half(s) for s in ("users", "items"))

@@ -157,15 +157,18 @@ int wmf_launch_gram(const float* Y, int64_t m, int f, int ld, int bias, double* 
 // Single workgroup.  A (fp64, row stride lda odd) lives in LDS when it fits, else in the global
 // workspace.  Right-looking Cholesky with one thread per trailing column, then the in-place
 // inverse of the lower triangle (column by column from the last), then the two fp32 outputs.
+// USE_LDS is a template parameter so that the matrix pointer keeps its address space: through a generic
+// pointer every access becomes a flat_load that waits for both memory counters (measured 10x slower).
+template <bool USE_LDS>
 __global__ __launch_bounds__(256) void factorize_kernel(const double* __restrict__ G, int f, int ld, double lambda,
                                                         float* __restrict__ Wwhite, float* __restrict__ Wunwhite,
-                                                        int32_t* __restrict__ info, double* __restrict__ gA, int use_lds) {
+                                                        int32_t* __restrict__ info, double* __restrict__ gA) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* A = use_lds ? reinterpret_cast<double*>(smem_raw) : gA;
     const int lda = f | 1;
     const int t = threadIdx.x;
     // the flag lives behind the matrix in the dynamic region (no static LDS in front of it)
-    volatile int& s_fail = *reinterpret_cast<volatile int*>(smem_raw + (use_lds ? (size_t)f * lda * sizeof(double) : 0));
+    volatile int& s_fail = *reinterpret_cast<volatile int*>(smem_raw + (USE_LDS ? (size_t)f * lda * sizeof(double) : 0));
+    auto body = [&](auto* A) {
     if (t == 0) s_fail = 0;
     for (int e = t; e < f * f; e += 256) {
         const int i = e / f, j = e % f;
@@ -243,21 +246,28 @@ __global__ __launch_bounds__(256) void factorize_kernel(const double* __restrict
         Wunwhite[e] = wu;
         Wwhite[e] = ww;
     }
+    };
+    if constexpr (USE_LDS) body(reinterpret_cast<double*>(smem_raw));
+    else body(gA);
 }
 
 int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, float* Wwhite, float* Wunwhite,
                          int32_t* info, double* gA, hipStream_t st) {
     const int lda = f | 1;
     const size_t bytes = (size_t)f * lda * sizeof(double);
-    const int use_lds = bytes <= 150 * 1024;
+    const bool use_lds = bytes <= 150 * 1024;
     static bool attr_set = false;
     if (use_lds && !attr_set) {
-        (void)hipFuncSetAttribute((const void*)factorize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024 + 16);
+        (void)hipFuncSetAttribute((const void*)factorize_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024 + 16);
         attr_set = true;
     }
     WmfProfScope ps(WMF_SLOT_FACTORIZE, st);
-    hipLaunchKernelGGL(factorize_kernel, dim3(1), dim3(256), (use_lds ? bytes : 0) + 16, st, G_sum, f, ld, lambda, Wwhite,
-                       Wunwhite, info, gA, use_lds);
+    if (use_lds)
+        hipLaunchKernelGGL(factorize_kernel<true>, dim3(1), dim3(256), bytes + 16, st, G_sum, f, ld, lambda, Wwhite, Wunwhite,
+                           info, gA);
+    else
+        hipLaunchKernelGGL(factorize_kernel<false>, dim3(1), dim3(256), 16, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info, gA);
     return 0;
 }
 

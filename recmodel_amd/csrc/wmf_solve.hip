@@ -23,39 +23,84 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+// d_i += nf * bcast(s_i), bcast = the value of lane KK of each 16-lane DPP row (row_newbcast, gfx90a+),
+// as ONE v_fmac_f32_dpp per element (hipcc does not fold a DPP mov into the fma by itself).  The
+// leading s_nop covers the "VALU write -> DPP read" hazard for the first source; no source of a later
+// instruction is written by an earlier one in the block.
+template <int KK>
+__device__ __forceinline__ void fmac_bcast4(float& d0, float& d1, float& d2, float& d3, float s0, float s1, float s2,
+                                            float s3, float nf) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %1, %5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %2, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %3, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+                 : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(nf), "n"(KK));
+}
+
+// same with source == destination (every lane reads its row's lane KK before any lane is written)
+template <int KK>
+__device__ __forceinline__ void fmac_bcast4_self(float& d0, float& d1, float& d2, float& d3, float nf) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+                 : "v"(nf), "n"(KK));
+}
+
 // One Gauss-Jordan step on pivot K (compile time, so register indices and the DPP control are
 // static).  Row j is spread over the 4 lanes (r, q = 0..3); column K lives in lanes q = (K & 15) >> 2,
 // register (K >> 4) * 4 + (K & 3).
 template <int K, int NSETS>
-__device__ __forceinline__ void gj_step(float (&m)[NSETS][NSETS * 4], float (&p)[NSETS], int d, int lane, bool& bad) {
-    if (K < d) {                                    // d is wave-uniform
-        constexpr int DPP_ROW_NEWBCAST = 0x150;     // gfx90a+: lane n of each 16-lane row to the whole row
-        constexpr int ks = K >> 4, kk = K & 15, kq = kk >> 2, kreg = ks * 4 + (kk & 3);
-        const int r = lane & 15;
-        const float piv = readlane_f(m[ks][kreg], kk + 16 * kq);
-        if (!(piv > 0.25f)) bad = true;
-        const float inv = __builtin_amdgcn_rcpf(piv);
-        float pr[NSETS * 4];
+__device__ __forceinline__ void gj_step(float (&m)[NSETS][NSETS * 4], float (&p)[NSETS], const int (&baddr)[4], int r) {
+    constexpr int ks = K >> 4, kk = K & 15, kq = kk >> 2, kreg = ks * 4 + (kk & 3);
+    const float piv = readlane_f(m[ks][kreg], kk + 16 * kq);
+    const float inv = __builtin_amdgcn_rcpf(piv);
+    const float pkv = readlane_f(p[ks], kk);
+    // multiplier -M[j][K] / piv per row (M[j][K] sits in lane (r, kq): one ds_bpermute with a precomputed
+    // address); for the pivot row itself -(piv - 1) / piv, which turns row - f * row into row / piv (the
+    // normalised pivot row) without a select per element.  The other set goes first: it must read the
+    // pivot row before that row is rewritten.
+    if constexpr (NSETS == 2) {
+        constexpr int so = 1 - ks;
+        const float fo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(baddr[kq], __builtin_bit_cast(int, m[so][kreg])));
+        const float nf = -fo * inv;
 #pragma unroll
-        for (int c = 0; c < NSETS * 4; ++c) pr[c] = wmf_dpp<DPP_ROW_NEWBCAST + kk>(m[ks][c]) * inv;
-        const float pk = readlane_f(p[ks], kk) * inv;
+        for (int c4 = 0; c4 < NSETS; ++c4)       // m[so][c] += nf * (lane kk of this 16-lane row of m[ks][c])
+            fmac_bcast4<kk>(m[so][4 * c4], m[so][4 * c4 + 1], m[so][4 * c4 + 2], m[so][4 * c4 + 3], m[ks][4 * c4],
+                            m[ks][4 * c4 + 1], m[ks][4 * c4 + 2], m[ks][4 * c4 + 3], nf);
+        p[so] = fmaf(nf, pkv, p[so]);
+    }
+    {
+        float fk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(baddr[kq], __builtin_bit_cast(int, m[ks][kreg])));
+        fk = (r == kk) ? piv - 1.f : fk;
+        const float nf = -fk * inv;
 #pragma unroll
-        for (int s = 0; s < NSETS; ++s) {
-            // multiplier M[j][K]; for the pivot row itself use piv - 1, which turns row - f * (row * inv)
-            // into row * inv (the normalised pivot row) without a select per element
-            float fk = __shfl(m[s][kreg], r + 16 * kq);
-            if (s == ks) fk = (r == kk) ? piv - 1.f : fk;
-#pragma unroll
-            for (int c = 0; c < NSETS * 4; ++c) m[s][c] -= fk * pr[c];
-            p[s] -= fk * pk;
-        }
+        for (int c4 = 0; c4 < NSETS; ++c4)
+            fmac_bcast4_self<kk>(m[ks][4 * c4], m[ks][4 * c4 + 1], m[ks][4 * c4 + 2], m[ks][4 * c4 + 3], nf);
+        p[ks] = fmaf(nf, pkv, p[ks]);
     }
 }
 
-template <int NSETS, int... Ks>
-__device__ __forceinline__ void gj_sweep(float (&m)[NSETS][NSETS * 4], float (&p)[NSETS], int d, int lane, bool& bad,
-                                         std::integer_sequence<int, Ks...>) {
-    (gj_step<Ks, NSETS>(m, p, d, lane, bad), ...);
+// Steps run in groups of four under one scalar branch.  A step past the row's last entry is a no-op
+// (its pivot row is an identity row, its column is zero everywhere else), so at most three are wasted.
+template <int G, int NSETS>
+__device__ __forceinline__ void gj_group(float (&m)[NSETS][NSETS * 4], float (&p)[NSETS], int d, const int (&baddr)[4],
+                                         int r) {
+    if (4 * G < d) {                                // d is wave-uniform (SGPR)
+        gj_step<4 * G, NSETS>(m, p, baddr, r);
+        gj_step<4 * G + 1, NSETS>(m, p, baddr, r);
+        gj_step<4 * G + 2, NSETS>(m, p, baddr, r);
+        gj_step<4 * G + 3, NSETS>(m, p, baddr, r);
+    }
+}
+template <int NSETS, int... Gs>
+__device__ __forceinline__ void gj_sweep(float (&m)[NSETS][NSETS * 4], float (&p)[NSETS], int d, const int (&baddr)[4],
+                                         int r, std::integer_sequence<int, Gs...>) {
+    (gj_group<Gs, NSETS>(m, p, d, baddr, r), ...);
 }
 
 // ------------------------------------------------------------------------------ low-degree rows
@@ -71,11 +116,16 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
                                                         const float* __restrict__ vals, int ld, float* __restrict__ g,
                                                         int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count) {
     const int lane = threadIdx.x & 63;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // wave-uniform values are forced into SGPRs: hipcc cannot see that threadIdx.x >> 6 is uniform, and
+    // would otherwise predicate every `k < d` step with exec masks and register copies
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     if (wid >= count) return;                       // whole wave exits together
-    const int u = rows[wid];
-    const int64_t lo = indptr[u];
-    const int d = (int)(indptr[u + 1] - lo);
+    const int u = __builtin_amdgcn_readfirstlane(rows[wid]);
+    const int64_t lo_v = indptr[u];
+    const int64_t lo = ((int64_t)__builtin_amdgcn_readfirstlane((int)(lo_v >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)lo_v);
+    const int d = __builtin_amdgcn_readfirstlane((int)(indptr[u + 1] - lo));
     const int r = lane & 15, q = lane >> 4;
     const int nch = ld >> 2;
 
@@ -141,9 +191,16 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
     // ---- Gauss-Jordan without pivoting on M (row-scaled SPD when w >= 0: pivots >= 1).
     //      Row j is spread over the 4 lanes (r, q = 0..3); column k lives in lanes q = (k & 15) >> 2,
     //      register (k >> 4) * 4 + (k & 3).  After the sweep M = I and p = M^-1 p = c.
+    int baddr[4];                                   // ds_bpermute byte address of lane (r, kq), kq = 0..3
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) baddr[kq] = (r + 16 * kq) * 4;
+    gj_sweep<NSETS>(m, p, d, baddr, r, std::make_integer_sequence<int, 4 * NSETS>{});
+    // With w >= 0 every pivot is >= 1 in exact arithmetic, so the sweep cannot break down; a NaN/Inf
+    // in the inputs is what is left to catch, and it survives into c.
     bool bad = false;
-    gj_sweep<NSETS>(m, p, d, lane, bad, std::make_integer_sequence<int, 16 * NSETS>{});
-    if (bad) {                                      // uniform (piv is a scalar)
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s) if (!(fabsf(p[s]) < 3.0e38f)) bad = true;
+    if (__any(bad)) {                               // wave-uniform: let the pivoted LU kernel report on the row
         if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;
         return;
     }
