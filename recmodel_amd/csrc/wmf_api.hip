@@ -85,7 +85,7 @@ int wmf_profile_read(double* ms, int64_t* launches) {
 const char* wmf_profile_slot_name(int slot) {
     static const char* names[WMF_PROF_SLOTS] = {"gram_kernel", "gram_reduce_kernel", "factorize_kernel", "transform_kernel",
         "solve_low_kernel<.,1>", "solve_low_kernel<.,2>", "solve_general_kernel(heavy)", "solve_general_kernel(fallback)",
-        "eval_kernel", "predict_kernel", "spmm_kernel", "solve_direct_kernel"};
+        "eval_kernel", "predict_kernel", "bias_adjust/spmm", "solve_direct_kernel"};
     return (slot >= 0 && slot < WMF_PROF_SLOTS) ? names[slot] : "?";
 }
 
@@ -185,6 +185,7 @@ void wmf_plan_destroy(wmf_plan* p) {
     if (p->rows_all) (void)hipFree(p->rows_all);
     if (p->fallback_rows) (void)hipFree(p->fallback_rows);
     if (p->fallback_count) (void)hipFree(p->fallback_count);
+    if (p->w_eff) (void)hipFree(p->w_eff);
     delete p;
 }
 

@@ -31,4 +31,32 @@ __device__ __forceinline__ double wmf_wave_sum_f64(double v) {
     return v;
 }
 
+// d_i += nf * bcast(s_i), bcast = the value of lane KK of each 16-lane DPP row (row_newbcast, gfx90a+),
+// as ONE v_fmac_f32_dpp per element (hipcc does not fold a DPP mov into the fma by itself).  The
+// leading s_nop covers the "VALU write -> DPP read" hazard for the first source; no source of a later
+// instruction is written by an earlier one in the block.
+template <int KK>
+__device__ __forceinline__ void fmac_bcast4(float& d0, float& d1, float& d2, float& d3, float s0, float s1, float s2,
+                                            float s3, float nf) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %1, %5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %2, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %3, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+                 : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(nf), "n"(KK));
+}
+
+// same with source == destination (every lane reads its row's lane KK before any lane is written)
+template <int KK>
+__device__ __forceinline__ void fmac_bcast4_self(float& d0, float& d1, float& d2, float& d3, float nf) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+                 : "v"(nf), "n"(KK));
+}
+
 static inline int wmf_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -15,6 +15,9 @@
 // Many independent waves per CU overlap one row's MFMA phase with another row's VALU phase.
 #include "wmf_common.h"
 #include "wmf_internal.h"
+#include "wmf_stream.h"
+
+#include <type_traits>
 
 __device__ __forceinline__ float rl64(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
@@ -37,49 +40,26 @@ __global__ __launch_bounds__(64, 3) void solve_direct64_kernel(const int32_t* __
     const int last_col = min(16 * (NFB - 1) + r, ld - 1);       // only the last feature block can run past ld
     const float last_mask = (16 * (NFB - 1) + r < ld) ? 1.f : 0.f;
 
-    // Row pipeline: the first loads of the NEXT row (its entry indices/weights and its first 16 factor
-    // rows) are requested before this row's factorisation starts, so their latency hides behind it.
-    float frC[4][NFB], frN[4][NFB], wC[4], mC[4], wN[4];
-    int idxN[4];
+    // Row pipeline (wmf_stream.h): factor rows are requested DEPTH groups ahead; the first loads of the
+    // NEXT row are requested before this row's factorisation starts, so their latency hides behind it.
+    constexpr int GS = 4, DEPTH = 3;
+    using Stream = WmfRowStream<NFB, GS, DEPTH>;
+    Stream st;
     int u = 0, d = 0;
     int64_t lo = 0;
     int64_t it = blockIdx.x;
     if (it < count) { u = rows[it]; lo = indptr[u]; d = (int)(indptr[u + 1] - lo); }
-
-    // Every load is unconditional (clamped to a stored entry) and its value is MULTIPLIED by a
-    // 0/1 mask: a select would let hipcc sink the load under a branch and wait for each in turn.
-    auto load_meta = [&](int64_t lo_, int d_, int G, int (&idx)[4], float (&w)[4]) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int j = 16 * G + 4 * t + q;
-            const float mask = j < d_ ? 1.f : 0.f;
-            const int64_t e = lo_ + max(min(j, d_ - 1), 0);
-            idx[t] = indices[e];
-            float wv = vals[e];
-            if (biasv) wv -= biasv[idx[t]];
-            w[t] = wv * mask;                                    // masked entries: weight 0 (their factor row is zeroed too)
-        }
+    auto prime = [&](int64_t lo_, int d_) {
+        st.load_block(0, lo_, d_, indices, vals, lane, 0);
+        st.load_block(1, lo_, d_, indices, vals, lane, 1);
+        st.template load_group<0>(0, V, ld, r, q, last_col);
+        st.template load_group<1>(1, V, ld, r, q, last_col);
+        st.template load_group<2>(2, V, ld, r, q, last_col);
     };
-    auto load_frags = [&](int d_, int G, const int (&idx)[4], float (&fr)[4][NFB]) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float mask = (16 * G + 4 * t + q < d_) ? 1.f : 0.f;
-            const float* vrow = V + (int64_t)idx[t] * ld;
-#pragma unroll
-            for (int fb = 0; fb < NFB - 1; ++fb) fr[t][fb] = vrow[16 * fb + r] * mask;
-            fr[t][NFB - 1] = vrow[last_col] * (mask * last_mask);
-        }
-    };
-    auto prologue = [&](int64_t lo_, int d_) {                   // groups 0 (meta + factor rows) and 1 (meta)
-        int idxC[4];
-        load_meta(lo_, d_, 0, idxC, wC);
-        load_frags(d_, 0, idxC, frC);
-        load_meta(lo_, d_, 1, idxN, wN);
-    };
-    if (it < count) prologue(lo, d);
+    if (it < count) prime(lo, d);
 
     for (; it < count; it += gridDim.x) {
-        const int ngroups = (d + 15) >> 4;                       // 16 entries = 4 MFMA k-steps per group
+        const int ngroups = (d + Stream::EPG - 1) / Stream::EPG;
         const int64_t itn = it + gridDim.x;
         int un = 0, dn = 0;
         int64_t lon = 0;
@@ -92,41 +72,37 @@ __global__ __launch_bounds__(64, 3) void solve_direct64_kernel(const int32_t* __
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) racc[fb] = 0.f;
 
-        auto mfma_group = [&](const float (&fr)[4][NFB], const float (&w)[4], const float (&m)[4]) {
+        // consume ring slot S (group G), then refill it with group G + DEPTH
+        auto step = [&](auto slot, int G) {
+            constexpr int S = decltype(slot)::value;
+            if (G >= ngroups) return;
+            if (!(dbg & 2)) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float fw[NFB];
+                for (int t = 0; t < GS; ++t) {
+                    float fw[NFB];
+                    st.fr[S][t][NFB - 1] *= last_mask;
 #pragma unroll
-                for (int fb = 0; fb < NFB; ++fb) { fw[fb] = fr[t][fb] * w[t]; racc[fb] += fr[t][fb] * (w[t] + m[t]); }
-                int tt = 0;
+                    for (int fb = 0; fb < NFB; ++fb) { fw[fb] = st.fr[S][t][fb] * st.w[S][t]; racc[fb] += st.fr[S][t][fb] * st.p[S][t]; }
+                    int tt = 0;
 #pragma unroll
-                for (int bi = 0; bi < NFB; ++bi)
+                    for (int bi = 0; bi < NFB; ++bi)
 #pragma unroll
-                    for (int bj = bi; bj < NFB; ++bj, ++tt) acc[tt] = WMF_MFMA16(fr[t][bi], fw[bj], acc[tt]);
-            }
-        };
-        // pipeline: meta (index, weight) two groups ahead, factor rows one group ahead
-        for (int G = 0; G < ngroups; ++G) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) mC[t] = (16 * G + 4 * t + q < d) ? 1.f : 0.f;       // p = w + 1 only for real entries
-            float wNext[4];
-            int idxNext[4];
-            if (G + 1 < ngroups) {
-                load_frags(d, G + 1, idxN, frN);                 // uses the meta requested one iteration ago
-#pragma unroll
-                for (int t = 0; t < 4; ++t) wNext[t] = wN[t];
-                if (G + 2 < ngroups) load_meta(lo, d, G + 2, idxNext, wN);
-            }
-            if (!(dbg & 2)) mfma_group(frC, wC, mC);
-            if (G + 1 < ngroups) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    wC[t] = wNext[t];
-                    if (G + 2 < ngroups) idxN[t] = idxNext[t];
-#pragma unroll
-                    for (int fb = 0; fb < NFB; ++fb) frC[t][fb] = frN[t][fb];
+                        for (int bj = bi; bj < NFB; ++bj, ++tt) acc[tt] = WMF_MFMA16(st.fr[S][t][bi], fw[bj], acc[tt]);
                 }
             }
+            const int next = G + DEPTH;
+            if (next < ngroups) {
+                if (next % Stream::GPB == 0) {                   // first group of block c: request block c + 1
+                    const int c = next / Stream::GPB;
+                    st.load_block(c + 1, lo, d, indices, vals, lane, (c + 1) & 1);
+                }
+                st.template load_group<S>(next, V, ld, r, q, last_col);
+            }
+        };
+        for (int G0 = 0; G0 < ngroups; G0 += DEPTH) {
+            step(std::integral_constant<int, 0>{}, G0);
+            step(std::integral_constant<int, 1>{}, G0 + 1);
+            step(std::integral_constant<int, 2>{}, G0 + 2);
         }
         // rhs: sum the four k-slot partials; every lane (r, *) then holds rhs[16 fb + r]
 #pragma unroll
@@ -155,7 +131,7 @@ __global__ __launch_bounds__(64, 3) void solve_direct64_kernel(const int32_t* __
         for (int fb = 0; fb < NFB; ++fb) { const float v = __shfl(racc[fb], r); b = (q == fb) ? v : b; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (itn < count) prologue(lon, dn);                      // in flight during the factorisation below
+        if (itn < count) prime(lon, dn);                         // in flight during the factorisation below
 
         // ---- C: left-looking blocked Cholesky; lane i owns row i while a panel is in registers
         bool ok = true;

@@ -1,0 +1,261 @@
+// Heavy rows for 64 < f <= 144 (k = 128 with or without biases): ONE WAVE PER ROW, the whole f x f
+// system lives in MFMA accumulator registers, no workgroup barriers (gfx950).
+//
+//   g_u = (I + V_u^T D V_u)^-1 V_u^T p          (RecModel/wmf_model.py:233-239 in whitened coordinates)
+//
+// Tile (bi, bj), bi <= bj, of B = I + V^T D V is one 16 x 16 accumulator: lane (r = l & 15, q = l >> 4)
+// holds B[16 bi + 4q + reg][16 bj + r].  The right-hand side is block column NFB.  One wave per SIMD
+// (up to 512 registers), four independent waves per CU.
+//   A. entries stream from HBM straight into operand registers (lane loads V[idx_{4s+q}][16 fb + r]),
+//      one 16-entry group ahead:  tile(bi,bj) += frag[bi]^T (w frag[bj]),  tile(bi,NFB) += frag[bi]^T (p in col 0).
+//   C. block elimination without square roots (B = U^T D U, D_p = the pivot blocks):
+//        X   = inverse of the diagonal tile -- a symmetric tile in accumulator layout IS the row-distributed
+//              layout of the Gauss-Jordan sweep of wmf_solve.hip, so it is inverted in place with 16
+//              v_fmac_dpp steps, and the result is already the MFMA A operand;
+//        W_pj = X B_pj  : four MFMAs with the tile's own registers as the B operand (k = 4q + reg);
+//        B_ij -= B_pi^T W_pj : both operands from a two-panel LDS buffer (originals and W), in place.
+//   D. g_p = w_p - sum_{j>p} W_pj g_j with DPP row sums; no triangular solves are left.
+// A non-positive pivot (system not positive definite: possible with biases) bounces the row to the
+// pivoted LU kernel.
+#include "wmf_common.h"
+#include "wmf_internal.h"
+#include "wmf_stream.h"
+
+#include <type_traits>
+
+#include <utility>
+
+__device__ __forceinline__ float rlw(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+template <int NFB>
+__device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for bj = bi .. NFB"
+    return bi * (NFB + 1) - (bi * (bi - 1)) / 2 + (bj - bi);
+}
+
+// In-place Gauss-Jordan inverse of a symmetric positive definite 16 x 16 tile held row-distributed:
+// lane (r, q) has A[r][4q + reg] in a[reg].  Step K: column K becomes e_K first, then every row gets
+// row_i += nf_i * row_K with nf = -A[i][K]/piv (rows i != K) or 1/piv - 1 (row K).
+template <int K>
+__device__ __forceinline__ void gj_inv_step(f32x4& a, const int (&baddr)[4], int r, int q, bool& ok) {
+    constexpr int kq = K >> 2, kr = K & 3;
+    const float akr = a[kr];     // copy first: __builtin_bit_cast applied to the vector-element lvalue itself reads element 0
+    const float piv = rlw(akr, K + 16 * kq);
+    if (!(piv > 1e-20f)) ok = false;
+    const float inv = __builtin_amdgcn_rcpf(piv);
+    const float fk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(baddr[kq], __builtin_bit_cast(int, akr)));
+    if (q == kq) a[kr] = (r == K) ? 1.f : 0.f;
+    const float nf = (r == K) ? inv - 1.f : -fk * inv;
+    float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+    fmac_bcast4_self<K>(a0, a1, a2, a3, nf);
+    a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3;
+}
+template <int... Ks>
+__device__ __forceinline__ void gj_inv_sweep(f32x4& a, const int (&baddr)[4], int r, int q, bool& ok,
+                                             std::integer_sequence<int, Ks...>) {
+    (gj_inv_step<Ks>(a, baddr, r, q, ok), ...);
+}
+
+template <int NFB>
+__global__ __launch_bounds__(64, 1) void solve_directw_kernel(const int32_t* __restrict__ rows, int64_t count,
+                                                              const float* __restrict__ V, const float* __restrict__ biasv,
+                                                              const int64_t* __restrict__ indptr,
+                                                              const int32_t* __restrict__ indices,
+                                                              const float* __restrict__ vals, int f, int ld,
+                                                              float* __restrict__ g, int32_t* __restrict__ fb_rows,
+                                                              int32_t* __restrict__ fb_count, int dbg) {
+    constexpr int NT = NFB * (NFB + 1) / 2 + NFB;
+    constexpr int GS = 2;                                        // MFMA k-steps (4 entries each) per pipelined group
+    __shared__ __attribute__((aligned(16))) float Pan1[(NFB + 1) * 320];     // original tiles of block row p
+    __shared__ __attribute__((aligned(16))) float Pan2[(NFB + 1) * 320];     // W tiles of block row p
+    const int lane = threadIdx.x;
+    const int r = lane & 15, q = lane >> 4;
+    const int last_col = min(16 * (NFB - 1) + r, ld - 1);       // only the last feature block can run past ld
+    const float last_mask = (16 * (NFB - 1) + r < ld) ? 1.f : 0.f;
+    int baddr[4];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) baddr[kq] = (r + 16 * kq) * 4;
+
+    // Row pipeline (wmf_stream.h): factor rows are requested DEPTH groups ahead; the next row's first loads
+    // are requested before this row's elimination starts.
+    constexpr int DEPTH = 3;
+    using Stream = WmfRowStream<NFB, GS, DEPTH>;
+    Stream st;
+    int u = 0, d = 0;
+    int64_t lo = 0;
+    int64_t it = blockIdx.x;
+    if (it < count) { u = rows[it]; lo = indptr[u]; d = (int)(indptr[u + 1] - lo); }
+    auto prime = [&](int64_t lo_, int d_) {
+        st.load_block(0, lo_, d_, indices, vals, lane, 0);
+        st.load_block(1, lo_, d_, indices, vals, lane, 1);
+        st.template load_group<0>(0, V, ld, r, q, last_col);
+        st.template load_group<1>(1, V, ld, r, q, last_col);
+        st.template load_group<2>(2, V, ld, r, q, last_col);
+    };
+    if (it < count) prime(lo, d);
+
+    for (; it < count; it += gridDim.x) {
+        const int ngroups = (d + Stream::EPG - 1) / Stream::EPG;
+        const int64_t itn = it + gridDim.x;
+        int un = 0, dn = 0;
+        int64_t lon = 0;
+        if (itn < count) { un = rows[itn]; lon = indptr[un]; dn = (int)(indptr[un + 1] - lon); }
+
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float racc[NFB];
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) racc[fb] = 0.f;
+
+        // ---- A (the rhs V^T p rides on the VALU and becomes block column NFB afterwards)
+        auto step = [&](auto slot, int G) {
+            constexpr int S = decltype(slot)::value;
+            if (G >= ngroups) return;
+            if (!(dbg & 2)) {
+#pragma unroll
+                for (int t = 0; t < GS; ++t) {
+                    float fw[NFB];
+                    st.fr[S][t][NFB - 1] *= last_mask;
+#pragma unroll
+                    for (int fb = 0; fb < NFB; ++fb) { fw[fb] = st.fr[S][t][fb] * st.w[S][t]; racc[fb] += st.fr[S][t][fb] * st.p[S][t]; }
+                    int tt = 0;
+#pragma unroll
+                    for (int bi = 0; bi < NFB; ++bi) {
+#pragma unroll
+                        for (int bj = bi; bj < NFB; ++bj, ++tt) acc[tt] = WMF_MFMA16(st.fr[S][t][bi], fw[bj], acc[tt]);
+                        ++tt;                                    // slot of the rhs tile (bi, NFB)
+                    }
+                }
+            }
+            const int next = G + DEPTH;
+            if (next < ngroups) {
+                if (next % Stream::GPB == 0) {
+                    const int c = next / Stream::GPB;
+                    st.load_block(c + 1, lo, d, indices, vals, lane, (c + 1) & 1);
+                }
+                st.template load_group<S>(next, V, ld, r, q, last_col);
+            }
+        };
+        for (int G0 = 0; G0 < ngroups; G0 += DEPTH) {
+            step(std::integral_constant<int, 0>{}, G0);
+            step(std::integral_constant<int, 1>{}, G0 + 1);
+            step(std::integral_constant<int, 2>{}, G0 + 2);
+        }
+        // rhs[16 fb + r] on every lane (r, *), then into column 0 of the rhs tiles: lane (0, q) needs rows 4q + reg
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+            racc[fb] += __shfl_xor(racc[fb], 16);
+            racc[fb] += __shfl_xor(racc[fb], 32);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float v = __shfl(racc[fb], 4 * q + reg);
+                acc[tile_w<NFB>(fb, NFB)][reg] = (r == 0) ? v : 0.f;
+            }
+        }
+        if (itn < count) prime(lon, dn);                         // next row's first loads fly during the elimination
+
+        // ---- C: block elimination, everything in registers except the two panel buffers
+        bool ok = true;
+        if (!(dbg & 1)) {
+#pragma unroll
+            for (int b = 0; b < NFB; ++b) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) if (r == 4 * q + reg) acc[tile_w<NFB>(b, b)][reg] += 1.f;
+            }
+#pragma unroll
+            for (int p = 0; p < NFB; ++p) {
+                f32x4 X = acc[tile_w<NFB>(p, p)];
+                gj_inv_sweep(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = p + 1; j <= NFB; ++j) {
+                    const int t = tile_w<NFB>(p, j);
+                    f32x4 n = f32x4{0.f, 0.f, 0.f, 0.f};
+                    n = WMF_MFMA16(X[0], acc[t][0], n); n = WMF_MFMA16(X[1], acc[t][1], n);
+                    n = WMF_MFMA16(X[2], acc[t][2], n); n = WMF_MFMA16(X[3], acc[t][3], n);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        Pan1[j * 320 + (4 * q + reg) * 20 + r] = acc[t][reg];
+                        Pan2[j * 320 + (4 * q + reg) * 20 + r] = n[reg];
+                    }
+                    acc[t] = n;                                  // W_pj stays in registers for the backward pass
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = p + 1; i < NFB; ++i) {
+                    float a[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = -Pan1[i * 320 + (4 * q + e) * 20 + r];
+#pragma unroll
+                    for (int j = i; j <= NFB; ++j) {
+                        const int t = tile_w<NFB>(i, j);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[t] = WMF_MFMA16(a[e], Pan2[j * 320 + (4 * q + e) * 20 + r], acc[t]);
+                    }
+                }
+            }
+        }
+        // ---- D: g_p = w_p - sum_{j > p} W_pj g_j ; gb[j] = g_j[lane & 15] on every lane
+        float gb[NFB];
+        if (!(dbg & 1)) {
+#pragma unroll
+            for (int p = NFB - 1; p >= 0; --p) {
+                float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = p + 1; j < NFB; ++j) {
+                    const int t = tile_w<NFB>(p, j);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) s[reg] += acc[t][reg] * gb[j];
+                }
+                float gsel = 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float w = wmf_dpp<0x150>(acc[tile_w<NFB>(p, NFB)][reg]);       // column 0 of the rhs tile -> whole row
+                    const float gv = w - ((p + 1 < NFB) ? wmf_row16_sum(s[reg]) : 0.f);  // g_p[4q + reg] on every lane (., q)
+                    gsel = ((r & 3) == reg) ? gv : gsel;
+                }
+                gb[p] = __shfl(gsel, 16 * (r >> 2) + (r & 3)); // g_p[r] sits in q-group r >> 2, in a lane whose r & 3 matches
+            }
+        }
+        if (!ok) {
+            if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;
+        } else if (q == 0) {
+#pragma unroll
+            for (int p = 0; p < NFB; ++p) {
+                const int c = 16 * p + r;
+                if (c < ld) g[(int64_t)u * ld + c] = (c < f) ? gb[p] : 0.f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        u = un; lo = lon; d = dn;
+    }
+}
+
+template <int NFB>
+static void launch_directw_nfb(const int32_t* rows, int64_t count, const float* V, const float* biasv,
+                               const int64_t* indptr, const int32_t* indices, const float* vals, int f, int ld, float* g,
+                               int32_t* fb_rows, int32_t* fb_count, int dbg, hipStream_t st) {
+    int64_t grid = 256 * 4 * 4;                                  // 4 waves per CU resident (one per SIMD), four rounds queued
+    if (grid > count) grid = count;
+    hipLaunchKernelGGL((solve_directw_kernel<NFB>), dim3((unsigned)grid), dim3(64), 0, st, rows, count, V, biasv, indptr,
+                       indices, vals, f, ld, g, fb_rows, fb_count, dbg);
+}
+
+int wmf_launch_directw(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
+                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
+                       int32_t* fb_count, hipStream_t st) {
+    if (count <= 0) return 0;
+    const int dbg = wmf_debug_flags;
+    switch ((f + 15) / 16) {
+#define C_(N) case N: launch_directw_nfb<N>(rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, st); break;
+        C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9)
+#undef C_
+        default: return -1;
+    }
+    return 0;
+}

@@ -18,6 +18,7 @@ struct wmf_plan {
     int32_t* rows_all;         // device: n row ids grouped by bin
     int32_t* fallback_rows;    // device: n slots, rows bounced to the general kernel at run time
     int32_t* fallback_count;   // device: 1 counter
+    float* w_eff;              // device: nnz effective weights (values - bias[indices]), allocated on first biased solve
 };
 
 int wmf_gram_nwaves(int64_t m);
@@ -35,6 +36,9 @@ int wmf_direct_supported(int f);
 int wmf_launch_direct(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
                       int32_t* fb_count, hipStream_t st);
+int wmf_launch_directw(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
+                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
+                       int32_t* fb_count, hipStream_t st);
 int wmf_launch_direct64(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                         const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
                         int32_t* fb_count, hipStream_t st);
@@ -54,7 +58,7 @@ extern int wmf_debug_flags;   // timing experiments only (tools/kernel_lab.py); 
 enum {
     WMF_SLOT_GRAM = 0, WMF_SLOT_GRAM_REDUCE, WMF_SLOT_FACTORIZE, WMF_SLOT_TRANSFORM, WMF_SLOT_SOLVE_LOW16,
     WMF_SLOT_SOLVE_LOW32, WMF_SLOT_SOLVE_HEAVY, WMF_SLOT_SOLVE_FALLBACK, WMF_SLOT_EVAL, WMF_SLOT_PREDICT,
-    WMF_SLOT_SPMM, WMF_SLOT_SOLVE_DIRECT
+    WMF_SLOT_OTHER, WMF_SLOT_SOLVE_DIRECT
 };
 void wmf_prof_begin(int slot, hipStream_t st);
 void wmf_prof_end(hipStream_t st);

@@ -23,34 +23,6 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-// d_i += nf * bcast(s_i), bcast = the value of lane KK of each 16-lane DPP row (row_newbcast, gfx90a+),
-// as ONE v_fmac_f32_dpp per element (hipcc does not fold a DPP mov into the fma by itself).  The
-// leading s_nop covers the "VALU write -> DPP read" hazard for the first source; no source of a later
-// instruction is written by an earlier one in the block.
-template <int KK>
-__device__ __forceinline__ void fmac_bcast4(float& d0, float& d1, float& d2, float& d3, float s0, float s1, float s2,
-                                            float s3, float nf) {
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f32_dpp %0, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %1, %5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %2, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %3, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
-                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
-                 : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(nf), "n"(KK));
-}
-
-// same with source == destination (every lane reads its row's lane KK before any lane is written)
-template <int KK>
-__device__ __forceinline__ void fmac_bcast4_self(float& d0, float& d1, float& d2, float& d3, float nf) {
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f32_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
-                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
-                 : "v"(nf), "n"(KK));
-}
-
 // One Gauss-Jordan step on pivot K (compile time, so register indices and the DPP control are
 // static).  Row j is spread over the 4 lanes (r, q = 0..3); column K lives in lanes q = (K & 15) >> 2,
 // register (K >> 4) * 4 + (K & 3).
@@ -375,9 +347,19 @@ int wmf_launch_spmm(const float* V, const int64_t* indptr, const int32_t* indice
     if (n <= 0) return 0;
     int64_t grid = (n + 3) / 4;
     if (grid > 8192) grid = 8192;
-    WmfProfScope ps(WMF_SLOT_SPMM, st);
+    WmfProfScope ps(WMF_SLOT_OTHER, st);
     hipLaunchKernelGGL(spmm_kernel, dim3((unsigned)grid), dim3(256), 0, st, V, indptr, indices, values, n, ld, g);
     return 0;
+}
+
+// ----------------------------------------------------------------------- bias-adjusted weights
+// w_eff[j] = values[j] - bias[indices[j]]   (RecModel/wmf_model.py:343), one streaming pass per half step,
+// so that the row kernels never chain a dependent gather behind their index loads.
+__global__ __launch_bounds__(256) void bias_adjust_kernel(const float* __restrict__ vals, const int32_t* __restrict__ indices,
+                                                          const float* __restrict__ biasv, int64_t nnz,
+                                                          float* __restrict__ w_eff) {
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * 256)
+        w_eff[j] = vals[j] - biasv[indices[j]];
 }
 
 // ------------------------------------------------------------------------------------- launchers
@@ -431,8 +413,19 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
                      const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fail_count,
                      hipStream_t st) {
     if (hipMemsetAsync(pl->fallback_count, 0, sizeof(int32_t), st) != hipSuccess) return -2;
-    if (pl->nnz[0] + pl->nnz[1] + pl->nnz[2] + pl->nnz[3] == 0)      // nothing stored: every row solves to zero
+    const int64_t nnz = pl->nnz[0] + pl->nnz[1] + pl->nnz[2] + pl->nnz[3];
+    if (nnz == 0)                                                      // nothing stored: every row solves to zero
         return hipMemsetAsync(g, 0, (size_t)pl->n * ld * sizeof(float), st) == hipSuccess ? 0 : -2;
+    if (biasv) {                                                       // fold the fixed side's biases into the weights once
+        wmf_plan* plm = const_cast<wmf_plan*>(pl);
+        if (!plm->w_eff && hipMalloc((void**)&plm->w_eff, (size_t)nnz * sizeof(float)) != hipSuccess) return -2;
+        int64_t grid = (nnz + 255) / 256;
+        if (grid > 8192) grid = 8192;
+        WmfProfScope ps(WMF_SLOT_OTHER, st);
+        hipLaunchKernelGGL(bias_adjust_kernel, dim3((unsigned)grid), dim3(256), 0, st, vals, indices, biasv, nnz, plm->w_eff);
+        vals = plm->w_eff;
+        biasv = nullptr;
+    }
     switch ((ld + 15) / 16) {
 #define C(N) case N: launch_low<N>(pl, V, biasv, indptr, indices, vals, ld, g, st); break;
         C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)
@@ -442,10 +435,11 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
     const bool general_ok = f <= 144;
     if (pl->count[WMF_BIN_MFMA] > 0) {
         WmfProfScope ps(WMF_SLOT_SOLVE_DIRECT, st);
-        const bool one_wave = f <= 64 && !(wmf_debug_flags & 16);
-        if ((one_wave ? wmf_launch_direct64 : wmf_launch_direct)(pl->rows[WMF_BIN_MFMA], pl->count[WMF_BIN_MFMA], V, biasv,
-                                                                 indptr, indices, vals, f, ld, g, pl->fallback_rows,
-                                                                 pl->fallback_count, st)) return -1;
+        // f <= 64: one wave per row with an LDS image; wider: one wave per row with the system in registers.
+        // (debug flag 16 selects the workgroup-per-row kernel, kept for A/B timing.)
+        auto fn = (wmf_debug_flags & 16) ? wmf_launch_direct : (f <= 64 ? wmf_launch_direct64 : wmf_launch_directw);
+        if (fn(pl->rows[WMF_BIN_MFMA], pl->count[WMF_BIN_MFMA], V, biasv, indptr, indices, vals, f, ld, g,
+               pl->fallback_rows, pl->fallback_count, st)) return -1;
     }
     if (pl->count[WMF_BIN_GENERAL] > 0) {
         if (!general_ok) return -1;

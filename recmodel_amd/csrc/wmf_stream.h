@@ -1,0 +1,58 @@
+// Per-wave streaming of one CSR row's entries into MFMA operand registers (gfx950), shared by the
+// one-wave-per-row direct kernels.
+//
+// Lane (r = l & 15, q = l >> 4).  MFMA k-step t of group g consumes the four entries 4 GS g + 4 t + q
+// (q = 0..3 are the four k slots); its A/B operand for feature block fb is V[idx][16 fb + r].
+//   * entry metadata travels in BLOCKS of 64 entries: lane l keeps (index, weight, p = weight + 1) of entry
+//     64 c + l, two blocks resident; a group picks its four entries out of the block with ds_bpermute.
+//     Entries past the row's end are clamped to the last real entry and get weight 0 and p 0, which
+//     cancels them in every product (the factor row they read is real, finite data).
+//   * factor rows are requested D groups ahead into a ring of D register sets.  The loads are RAW: nothing
+//     touches the destination registers until the group is consumed, so the only s_waitcnt for them
+//     sits in front of the MFMAs that use them, D - 1 groups of MFMA work after they were issued.
+// Every register-array index is a compile-time constant (the group loop is unrolled by D).
+#pragma once
+#include "wmf_common.h"
+
+template <int NFB, int GS, int D>
+struct WmfRowStream {
+    static constexpr int EPG = 4 * GS;            // entries per group
+    static constexpr int GPB = 64 / EPG;          // groups per 64-entry block
+    float fr[D][GS][NFB];                         // factor-row operands
+    float w[D][GS];                               // weight of the entry of (k-step t, slot q)
+    float p[D][GS];                               // w + 1 for real entries, 0 for padding
+    int idxB[2];
+    float wB[2], pB[2];
+
+    // block c of the row (lo, d): lane l <- entry 64 c + l
+    __device__ __forceinline__ void load_block(int c, int64_t lo, int d, const int32_t* __restrict__ indices,
+                                               const float* __restrict__ vals, int lane, int slot) {
+        const int j = 64 * c + lane;
+        const float mask = j < d ? 1.f : 0.f;
+        const int64_t e = lo + max(min(j, d - 1), 0);
+        const int idx = indices[e];
+        const float wv = vals[e];
+        if (slot == 0) { idxB[0] = idx; wB[0] = wv * mask; pB[0] = (wv + 1.f) * mask; }
+        else           { idxB[1] = idx; wB[1] = wv * mask; pB[1] = (wv + 1.f) * mask; }
+    }
+
+    // request the factor rows of group g into ring slot S (compile time)
+    template <int S>
+    __device__ __forceinline__ void load_group(int g, const float* __restrict__ V, int ld, int r, int q, int last_col) {
+        const int c = g / GPB;
+        const int idx_c = (c & 1) ? idxB[1] : idxB[0];
+        const float w_c = (c & 1) ? wB[1] : wB[0];
+        const float p_c = (c & 1) ? pB[1] : pB[0];
+#pragma unroll
+        for (int t = 0; t < GS; ++t) {
+            const int src = ((EPG * g + 4 * t + q) & 63) << 2;                       // ds_bpermute byte address
+            const int idx = __builtin_amdgcn_ds_bpermute(src, idx_c);
+            w[S][t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w_c)));
+            p[S][t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, p_c)));
+            const float* vrow = V + (int64_t)idx * ld;
+#pragma unroll
+            for (int fb = 0; fb < NFB - 1; ++fb) fr[S][t][fb] = vrow[16 * fb + r];
+            fr[S][t][NFB - 1] = vrow[last_col];                                      // masked by the consumer
+        }
+    }
+};
