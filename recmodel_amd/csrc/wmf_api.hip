@@ -96,7 +96,7 @@ int wmf_ld_for(int f) { return (f + 3) & ~3; }
 // ---- workspace layout of gram/factorize: [partials fp32][slices fp64 32 x f x f][A fp64 f x (f|1)] ----
 static int64_t gram_partial_bytes(int f) {
     const int64_t nfb = (f + 15) / 16, nt = nfb * (nfb + 1) / 2;
-    return (int64_t)WMF_GRAM_MAX_WAVES * nt * 256 * (int64_t)sizeof(float);
+    return (int64_t)wmf_gram_max_waves(f) * nt * 256 * (int64_t)sizeof(float);
 }
 static int64_t gram_slices_off(int f) { return (gram_partial_bytes(f) + 255) & ~(int64_t)255; }
 static int64_t gram_a_off(int f) { return (gram_slices_off(f) + (int64_t)32 * f * f * 8 + 255) & ~(int64_t)255; }

@@ -7,6 +7,8 @@
 #include "wmf_common.h"
 #include "wmf_internal.h"
 
+#include <utility>
+
 // ------------------------------------------------------------------------------------------ gram
 // One wave per workgroup.  A wave walks a contiguous range of 4-row steps; at each step lane
 // (r = l & 15, q = l >> 4) loads Y~[4s + q][16 fb + r] for every 16-column feature block fb.  The
@@ -23,27 +25,47 @@ __device__ __forceinline__ void gram_body(const float* __restrict__ Y, int64_t m
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int64_t s = step_lo; s < step_hi; ++s) {
-        const int64_t row = 4 * s + q;
-        const bool rok = row < m;
-        const float* yrow = Y + (rok ? row : 0) * (int64_t)ld;   // unconditional loads, masked afterwards
-        float frag[NFB];
+    // U steps (4 rows each) per trip; the loads of the next trip are issued before this trip's MFMAs and
+    // stay untouched until then (raw loads: masks and the bias column are applied at use).
+    constexpr int U = 4;
+    float cur[U][NFB], nxt[U][NFB];
+    const int last_col = min(16 * (NFB - 1) + r, ld - 1);
+    const float col_mask_last = (16 * (NFB - 1) + r < f) ? 1.f : 0.f;
+    auto load_trip = [&](int64_t s0, float (&fr)[U][NFB]) {
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) {
-            const int col = 16 * fb + r;
-            float v = yrow[min(col, ld - 1)];
-            v = (rok && col < f) ? v : 0.f;
-            if (bias && col == 0 && rok) v = 1.f;
-            frag[fb] = v;
+        for (int uu = 0; uu < U; ++uu) {
+            const int64_t row = min(4 * (s0 + uu) + q, m - 1);                        // clamped: masked at use
+            const float* yrow = Y + row * (int64_t)ld;
+#pragma unroll
+            for (int fb = 0; fb < NFB - 1; ++fb) fr[uu][fb] = yrow[16 * fb + r];
+            fr[uu][NFB - 1] = yrow[last_col];
         }
-        int t = 0;
+    };
+    if (step_lo < step_hi) load_trip(step_lo, cur);
+    for (int64_t s0 = step_lo; s0 < step_hi; s0 += U) {
+        if (s0 + U < step_hi) load_trip(s0 + U, nxt);
 #pragma unroll
-        for (int bi = 0; bi < NFB; ++bi) {
+        for (int uu = 0; uu < U; ++uu) {
+            const int64_t s = s0 + uu;
+            const float rmask = (s < step_hi && 4 * s + q < m) ? 1.f : 0.f;
+            float frag[NFB];
 #pragma unroll
-            for (int bj = bi; bj < NFB; ++bj, ++t) {
-                if (t % NSPLIT == S) acc[t / NSPLIT] = WMF_MFMA16(frag[bi], frag[bj], acc[t / NSPLIT]);
+            for (int fb = 0; fb < NFB; ++fb) frag[fb] = cur[uu][fb] * rmask;
+            frag[NFB - 1] *= col_mask_last;
+            if (bias && r == 0) frag[0] = rmask;                                     // column 0 reads as 1 (wmf_model.py:331)
+            int t = 0;
+#pragma unroll
+            for (int bi = 0; bi < NFB; ++bi) {
+#pragma unroll
+                for (int bj = bi; bj < NFB; ++bj, ++t) {
+                    if (t % NSPLIT == S) acc[t / NSPLIT] = WMF_MFMA16(frag[bi], frag[bj], acc[t / NSPLIT]);
+                }
             }
         }
+#pragma unroll
+        for (int uu = 0; uu < U; ++uu)
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) cur[uu][fb] = nxt[uu][fb];
     }
     // partial layout: [wave][tile][reg][lane]
     float* out = partial + (int64_t)blockIdx.x * NT * 256;
@@ -125,11 +147,19 @@ static int launch_gram_nfb(const float* Y, int64_t m, int f, int ld, int bias, f
     return 0;
 }
 
-int wmf_gram_nwaves(int64_t m) {
+int wmf_gram_max_waves(int f) {            // keep the per-wave partial tiles within 64 MiB
+    const int64_t nfb = (f + 15) / 16, nt = nfb * (nfb + 1) / 2;
+    int64_t cap = ((int64_t)64 << 20) / (nt * 1024);
+    if (cap > WMF_GRAM_MAX_WAVES) cap = WMF_GRAM_MAX_WAVES;
+    return (int)(cap < 64 ? 64 : cap);
+}
+
+int wmf_gram_nwaves(int64_t m, int f) {
     int64_t nsteps = (m + 3) / 4;
-    int64_t want = (nsteps + 63) / 64;     // at least 64 steps (256 rows) per wave
+    int64_t want = (nsteps + 31) / 32;     // at least 32 steps (128 rows) per wave
     if (want < 1) want = 1;
-    if (want > WMF_GRAM_MAX_WAVES) want = WMF_GRAM_MAX_WAVES;
+    const int cap = wmf_gram_max_waves(f);
+    if (want > cap) want = cap;
     return (int)want;
 }
 
@@ -137,7 +167,7 @@ int wmf_launch_gram(const float* Y, int64_t m, int f, int ld, int bias, double* 
                     hipStream_t st) {
     if (m <= 0) return hipMemsetAsync(G_sum, 0, (size_t)f * f * sizeof(double), st) == hipSuccess ? 0 : -1;
     const int nfb = (f + 15) / 16;
-    const int nwaves = wmf_gram_nwaves(m);
+    const int nwaves = wmf_gram_nwaves(m, f);
     WmfProfScope* ps = new WmfProfScope(WMF_SLOT_GRAM, st);
     switch (nfb) {
 #define C(N) case N: launch_gram_nfb<N>(Y, m, f, ld, bias, partial, nwaves, st); break;
@@ -251,8 +281,85 @@ __global__ __launch_bounds__(256) void factorize_kernel(const double* __restrict
     else body(gA);
 }
 
+// ---- f <= 64: one wave, one lane per matrix row, the whole fp64 matrix in registers ------------
+// Right-looking Cholesky with the pivot column broadcast by v_readlane (two halves per double), then
+// lane j builds column j of L^-1 by forward substitution.  No LDS, no barriers: ~10x faster than the
+// workgroup version at f = 64, where 2 x 64 barrier-separated steps are pure latency.
+__device__ __forceinline__ double rl_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+template <int K, int FP>
+__device__ __forceinline__ void chol64_col(double (&a)[FP], bool& ok) {
+    const double dk = rl_f64(a[K], K);
+    if (!(dk > 0.0)) ok = false;
+    const double inv = 1.0 / sqrt(dk);
+    a[K] *= inv;                                    // lane K: sqrt(dk); lanes > K: L[i][K]
+#pragma unroll
+    for (int j = K + 1; j < FP; ++j) a[j] -= a[K] * rl_f64(a[K], j);
+}
+template <int FP, int... Ks>
+__device__ __forceinline__ void chol64_sweep(double (&a)[FP], bool& ok, std::integer_sequence<int, Ks...>) {
+    (chol64_col<Ks, FP>(a, ok), ...);
+}
+template <int I, int FP>
+__device__ __forceinline__ void inv64_row(const double (&a)[FP], double (&x)[FP], int lane) {
+    double s = (I == lane) ? 1.0 : 0.0;             // X[I][lane] = (delta - sum_{k<I} L[I][k] X[k][lane]) / L[I][I]
+#pragma unroll
+    for (int k = 0; k < I; ++k) s -= rl_f64(a[k], I) * x[k];
+    x[I] = s / rl_f64(a[I], I);
+}
+template <int FP, int... Is>
+__device__ __forceinline__ void inv64_sweep(const double (&a)[FP], double (&x)[FP], int lane, std::integer_sequence<int, Is...>) {
+    (inv64_row<Is, FP>(a, x, lane), ...);
+}
+
+template <int FP>
+__global__ __launch_bounds__(64, 1) void factorize64_kernel(const double* __restrict__ G, int f, int ld, double lambda,
+                                                            float* __restrict__ Wwhite, float* __restrict__ Wunwhite,
+                                                            int32_t* __restrict__ info) {
+    const int lane = threadIdx.x;
+    double a[FP];
+#pragma unroll
+    for (int j = 0; j < FP; ++j) {
+        double v = (lane == j) ? 1.0 : 0.0;         // identity padding for rows / columns >= f
+        if (lane < f && j < f) v = G[lane * f + j] + (lane == j ? lambda : 0.0);
+        a[j] = v;
+    }
+    bool ok = true;
+    chol64_sweep<FP>(a, ok, std::make_integer_sequence<int, FP>{});
+    if (lane == 0) *info = ok ? 0 : 1;
+    double x[FP];
+    inv64_sweep<FP>(a, x, lane, std::make_integer_sequence<int, FP>{});
+    // lane j holds column j of X = L^-1:  Wunwhite[i][j] = X[i][j],  Wwhite[j][i] = X[i][j]
+    if (lane < f) {
+#pragma unroll
+        for (int i = 0; i < FP; ++i) {
+            if (i < f) {
+                const float v = ok ? (float)x[i] : 0.f;
+                Wunwhite[i * ld + lane] = v;
+                Wwhite[lane * ld + i] = v;
+            }
+        }
+    }
+    for (int e = lane; e < f * (ld - f); e += 64) {                      // zero padding columns [f, ld)
+        const int row = e / (ld - f), col = f + e % (ld - f);
+        Wunwhite[row * ld + col] = 0.f;
+        Wwhite[row * ld + col] = 0.f;
+    }
+}
+
 int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, float* Wwhite, float* Wunwhite,
                          int32_t* info, double* gA, hipStream_t st) {
+    if (f <= 64) {                                   // register-resident single-wave version
+        WmfProfScope ps(WMF_SLOT_FACTORIZE, st);
+        if (f <= 16) hipLaunchKernelGGL(factorize64_kernel<16>, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
+        else if (f <= 32) hipLaunchKernelGGL(factorize64_kernel<32>, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
+        else if (f <= 48) hipLaunchKernelGGL(factorize64_kernel<48>, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
+        else hipLaunchKernelGGL(factorize64_kernel<64>, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
+        return 0;
+    }
     const int lda = f | 1;
     const size_t bytes = (size_t)f * lda * sizeof(double);
     const bool use_lds = bytes <= 150 * 1024;

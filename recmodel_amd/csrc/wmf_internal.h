@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define WMF_GRAM_MAX_WAVES 1024
+#define WMF_GRAM_MAX_WAVES 4096
 #define WMF_EVAL_MAX_BLOCKS 2048
 
 // row-degree bins of a plan
@@ -21,7 +21,8 @@ struct wmf_plan {
     float* w_eff;              // device: nnz effective weights (values - bias[indices]), allocated on first biased solve
 };
 
-int wmf_gram_nwaves(int64_t m);
+int wmf_gram_max_waves(int f);
+int wmf_gram_nwaves(int64_t m, int f);
 int wmf_launch_gram(const float* Y, int64_t m, int f, int ld, int bias, double* G_sum, float* partial, double* slices,
                     hipStream_t st);
 int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, float* Wwhite, float* Wunwhite,

@@ -80,7 +80,7 @@ __device__ __forceinline__ void gj_sweep(float (&m)[NSETS][NSETS * 4], float (&p
 // r == j (set A) or r == j - 16 (set B, NSETS == 2).  Each lane loads 16-byte pieces
 // V[idx][16 t + 4 q .. +3]; element e of piece t is the MFMA operand of step (t, e) for k slot q.
 // Because S = V_u V_u^T, the same register is the A and the B operand.
-template <int NCH, int NSETS>
+template <int NCH, int NSETS, bool BLK>
 __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                         const float* __restrict__ V, const float* __restrict__ biasv,
                                                         const int64_t* __restrict__ indptr,
@@ -135,10 +135,12 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
         return;
     }
 
-    // ---- S blocks by MFMA.  m[s][c*4 + reg] = M[row j = r + 16 s][col 16 c + 4 q + reg],
-    //      M = I + D S.  acc layout: D[4q + reg][r]; S symmetric, so tile(a=x[c], b=x[s]) holds
-    //      S[set c row 4q+reg][set s row r] = S[set s row r][set c row 4q+reg].
-    float m[NSETS][NSETS * 4];
+    int baddr[4];                                   // ds_bpermute byte address of lane (r, kq), kq = 0..3
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) baddr[kq] = (r + 16 * kq) * 4;
+    // ---- S blocks by MFMA: Sb[s][c][reg] = S[row r + 16 s][col 16 c + 4 q + reg].  acc layout is D[4q + reg][r];
+    //      S symmetric, so tile(a = x[c], b = x[s]) = S[set c row 4q+reg][set s row r] = S[set s row r][set c row 4q+reg].
+    float Sb[NSETS][NSETS][4];
 #pragma unroll
     for (int s = 0; s < NSETS; ++s) {
 #pragma unroll
@@ -152,21 +154,76 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
                 a1 = WMF_MFMA16(x[c][t].w, x[s][t].w, a1);
             }
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float sij = a0[reg] + a1[reg];
-                const float diag = (s == c && r == 4 * q + reg) ? 1.f : 0.f;
-                m[s][c * 4 + reg] = w[s] * sij + diag;
-            }
+            for (int reg = 0; reg < 4; ++reg) Sb[s][c][reg] = a0[reg] + a1[reg];
         }
     }
-
-    // ---- Gauss-Jordan without pivoting on M (row-scaled SPD when w >= 0: pivots >= 1).
-    //      Row j is spread over the 4 lanes (r, q = 0..3); column k lives in lanes q = (k & 15) >> 2,
-    //      register (k >> 4) * 4 + (k & 3).  After the sweep M = I and p = M^-1 p = c.
-    int baddr[4];                                   // ds_bpermute byte address of lane (r, kq), kq = 0..3
+    if constexpr (BLK && NSETS == 2) {
+        // ---- symmetric form and 2 x 2 block elimination with 16 x 16 tiles:
+        //   c = p - E y,   (I + E S E) y = E S p,   E = diag(sqrt(w))        (equal to (I + D S)^-1 p)
+        //   P = [[A, U], [B, C]],  B = U^T:  X = A^-1 (tile Gauss-Jordan), T = B X and S' = C - T B^T by MFMA on the
+        //   row-distributed registers (MFMA(RD(X), RD(Y)) = RD(Y X^T)), then two tile solves for the vectors.
+        const float e0 = sqrtf(w[0]), e1 = sqrtf(w[1]);
+        const int caddr[4] = {(4 * q + 0) * 4, (4 * q + 1) * 4, (4 * q + 2) * 4, (4 * q + 3) * 4};   // lane of entry 4q + reg (q = 0 row)
+        auto col4 = [&](float v, float (&out)[4]) {             // out[reg] = value of row 4q + reg
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq) baddr[kq] = (r + 16 * kq) * 4;
-    gj_sweep<NSETS>(m, p, d, baddr, r, std::make_integer_sequence<int, 4 * NSETS>{});
+            for (int reg = 0; reg < 4; ++reg)
+                out[reg] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(caddr[reg], __builtin_bit_cast(int, v)));
+        };
+        auto qsum = [&](float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };
+        float eA[4], eB[4];
+        col4(e0, eA);
+        col4(e1, eB);
+        f32x4 PA, PU, PB, PC;
+        float spA = 0.f, spB = 0.f;                              // (S p) of my A row / my B row, partial over my columns
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float pa = eA[reg] * eA[reg] + 1.f, pb = eB[reg] * eB[reg] + 1.f;
+            spA += Sb[0][0][reg] * pa + Sb[0][1][reg] * pb;
+            spB += Sb[1][0][reg] * pa + Sb[1][1][reg] * pb;
+            const float dg = (r == 4 * q + reg) ? 1.f : 0.f;
+            PA[reg] = dg + e0 * Sb[0][0][reg] * eA[reg];
+            PU[reg] = e0 * Sb[0][1][reg] * eB[reg];
+            PB[reg] = e1 * Sb[1][0][reg] * eA[reg];
+            PC[reg] = dg + e1 * Sb[1][1][reg] * eB[reg];
+        }
+        const float tA = e0 * qsum(spA);
+        float tB = e1 * qsum(spB);
+        bool okb = true;
+        f32x4 X = PA;
+        gj_inv_sweep(X, baddr, r, q, okb, std::make_integer_sequence<int, 16>{});
+        f32x4 T = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T = WMF_MFMA16(X[e], PB[e], T);               // RD(B X)
+        f32x4 SC = PC;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) SC = WMF_MFMA16(-T[e], PB[e], SC);            // RD(C - T B^T), symmetric
+        float col[4];
+        col4(tA, col);
+        tB -= qsum(T[0] * col[0] + T[1] * col[1] + T[2] * col[2] + T[3] * col[3]);
+        float mS[1][4] = {{SC[0], SC[1], SC[2], SC[3]}};
+        float yv[1] = {tB};
+        gj_sweep<1>(mS, yv, d - 16, baddr, r, std::make_integer_sequence<int, 4>{});   // rows past d - 16 are identity rows
+        const float yB = yv[0];
+        col4(yB, col);
+        const float z = tA - qsum(PU[0] * col[0] + PU[1] * col[1] + PU[2] * col[2] + PU[3] * col[3]);
+        col4(z, col);
+        const float yA = qsum(X[0] * col[0] + X[1] * col[1] + X[2] * col[2] + X[3] * col[3]);
+        p[0] -= e0 * yA;
+        p[1] -= e1 * yB;
+        if (!okb) p[0] = __builtin_nanf("");                     // caught by the finite check below
+    } else {
+        // ---- M = I + D S row-distributed: m[s][c*4 + reg] = M[row r + 16 s][col 16 c + 4 q + reg]; Gauss-Jordan
+        //      without pivoting (row-scaled SPD when w >= 0: pivots >= 1).  After the sweep p = M^-1 p = c.
+        float m[NSETS][NSETS * 4];
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s)
+#pragma unroll
+            for (int c = 0; c < NSETS; ++c)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    m[s][c * 4 + reg] = w[s] * Sb[s][c][reg] + ((s == c && r == 4 * q + reg) ? 1.f : 0.f);
+        gj_sweep<NSETS>(m, p, d, baddr, r, std::make_integer_sequence<int, 4 * NSETS>{});
+    }
     // With w >= 0 every pivot is >= 1 in exact arithmetic, so the sweep cannot break down; a NaN/Inf
     // in the inputs is what is left to catch, and it survives into c.
     bool bad = false;
@@ -369,15 +426,20 @@ static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, c
     const int64_t c0 = pl->count[WMF_BIN_LOW16], c1 = pl->count[WMF_BIN_LOW32];
     if (c0 > 0) {
         WmfProfScope ps(WMF_SLOT_SOLVE_LOW16, st);
-        hipLaunchKernelGGL((solve_low_kernel<NCH, 1>), dim3((unsigned)((c0 + 3) / 4)), dim3(256), 0, st,
+        hipLaunchKernelGGL((solve_low_kernel<NCH, 1, false>), dim3((unsigned)((c0 + 3) / 4)), dim3(256), 0, st,
                            pl->rows[WMF_BIN_LOW16], c0, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
                            pl->fallback_count);
     }
     if (c1 > 0) {
         WmfProfScope ps(WMF_SLOT_SOLVE_LOW32, st);
-        hipLaunchKernelGGL((solve_low_kernel<NCH, 2>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
-                           pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
-                           pl->fallback_count);
+        if (wmf_debug_flags & 64)       // plain 32 x 32 Gauss-Jordan, kept for A/B timing
+            hipLaunchKernelGGL((solve_low_kernel<NCH, 2, false>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
+                               pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
+                               pl->fallback_count);
+        else
+            hipLaunchKernelGGL((solve_low_kernel<NCH, 2, true>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
+                               pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
+                               pl->fallback_count);
     }
 }
 
