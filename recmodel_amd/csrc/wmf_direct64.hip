@@ -52,6 +52,7 @@ __global__ __launch_bounds__(64, 3) void solve_direct64_kernel(const int32_t* __
     auto prime = [&](int64_t lo_, int d_) {
         st.load_block(0, lo_, d_, indices, vals, lane, 0);
         st.load_block(1, lo_, d_, indices, vals, lane, 1);
+        st.fetch_meta(0, q);
         st.template load_group<0>(0, V, ld, r, q, last_col);
         st.template load_group<1>(1, V, ld, r, q, last_col);
         st.template load_group<2>(2, V, ld, r, q, last_col);

@@ -31,7 +31,7 @@ __device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for
 }
 
 template <int NFB>
-__global__ __launch_bounds__(64, 1) void solve_directw_kernel(const int32_t* __restrict__ rows, int64_t count,
+__global__ __launch_bounds__(64, (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1))) void solve_directw_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                               const float* __restrict__ V, const float* __restrict__ biasv,
                                                               const int64_t* __restrict__ indptr,
                                                               const int32_t* __restrict__ indices,
@@ -62,6 +62,7 @@ __global__ __launch_bounds__(64, 1) void solve_directw_kernel(const int32_t* __r
     auto prime = [&](int64_t lo_, int d_) {
         st.load_block(0, lo_, d_, indices, vals, lane, 0);
         st.load_block(1, lo_, d_, indices, vals, lane, 1);
+        st.fetch_meta(0, q);
         st.template load_group<0>(0, V, ld, r, q, last_col);
         st.template load_group<1>(1, V, ld, r, q, last_col);
         st.template load_group<2>(2, V, ld, r, q, last_col);
@@ -213,7 +214,8 @@ template <int NFB>
 static void launch_directw_nfb(const int32_t* rows, int64_t count, const float* V, const float* biasv,
                                const int64_t* indptr, const int32_t* indices, const float* vals, int f, int ld, float* g,
                                int32_t* fb_rows, int32_t* fb_count, int dbg, hipStream_t st) {
-    int64_t grid = 256 * 4 * 4;                                  // 4 waves per CU resident (one per SIMD), four rounds queued
+    constexpr int waves_per_cu = 4 * (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1));
+    int64_t grid = 256 * waves_per_cu * 3;                       // resident waves, three rounds queued
     if (grid > count) grid = count;
     hipLaunchKernelGGL((solve_directw_kernel<NFB>), dim3((unsigned)grid), dim3(64), 0, st, rows, count, V, biasv, indptr,
                        indices, vals, f, ld, g, fb_rows, fb_count, dbg);
@@ -226,7 +228,7 @@ int wmf_launch_directw(const int32_t* rows, int64_t count, const float* V, const
     const int dbg = wmf_debug_flags;
     switch ((f + 15) / 16) {
 #define C_(N) case N: launch_directw_nfb<N>(rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, st); break;
-        C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9)
+        C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9)
 #undef C_
         default: return -1;
     }

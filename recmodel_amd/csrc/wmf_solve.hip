@@ -497,9 +497,11 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
     const bool general_ok = f <= 144;
     if (pl->count[WMF_BIN_MFMA] > 0) {
         WmfProfScope ps(WMF_SLOT_SOLVE_DIRECT, st);
-        // f <= 64: one wave per row with an LDS image; wider: one wave per row with the system in registers.
-        // (debug flag 16 selects the workgroup-per-row kernel, kept for A/B timing.)
-        auto fn = (wmf_debug_flags & 16) ? wmf_launch_direct : (f <= 64 ? wmf_launch_direct64 : wmf_launch_directw);
+        // One wave per row with the whole system in MFMA accumulator registers (wmf_directw.hip).  Debug flags
+        // select the two earlier designs, kept for A/B timing: 16 = workgroup per row (wmf_direct.hip),
+        // 128 = one wave per row with an LDS image of the matrix (wmf_direct64.hip, f <= 64 only).
+        auto fn = (wmf_debug_flags & 16) ? wmf_launch_direct
+                  : ((f <= 64 && (wmf_debug_flags & 128)) ? wmf_launch_direct64 : wmf_launch_directw);
         if (fn(pl->rows[WMF_BIN_MFMA], pl->count[WMF_BIN_MFMA], V, biasv, indptr, indices, vals, f, ld, g,
                pl->fallback_rows, pl->fallback_count, st)) return -1;
     }

@@ -23,6 +23,8 @@ struct WmfRowStream {
     float p[D][GS];                               // w + 1 for real entries, 0 for padding
     int idxB[2];
     float wB[2], pB[2];
+    int idxM[GS];                                 // metadata of the next group to be requested (fetched one call early,
+    float wM[GS], pM[GS];                         // so the ds_bpermute latency is off the address path)
 
     // block c of the row (lo, d): lane l <- entry 64 c + l
     __device__ __forceinline__ void load_block(int c, int64_t lo, int d, const int32_t* __restrict__ indices,
@@ -36,9 +38,8 @@ struct WmfRowStream {
         else           { idxB[1] = idx; wB[1] = wv * mask; pB[1] = (wv + 1.f) * mask; }
     }
 
-    // request the factor rows of group g into ring slot S (compile time)
-    template <int S>
-    __device__ __forceinline__ void load_group(int g, const float* __restrict__ V, int ld, int r, int q, int last_col) {
+    // pick the entries of group g out of their (resident) block
+    __device__ __forceinline__ void fetch_meta(int g, int q) {
         const int c = g / GPB;
         const int idx_c = (c & 1) ? idxB[1] : idxB[0];
         const float w_c = (c & 1) ? wB[1] : wB[0];
@@ -46,13 +47,25 @@ struct WmfRowStream {
 #pragma unroll
         for (int t = 0; t < GS; ++t) {
             const int src = ((EPG * g + 4 * t + q) & 63) << 2;                       // ds_bpermute byte address
-            const int idx = __builtin_amdgcn_ds_bpermute(src, idx_c);
-            w[S][t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w_c)));
-            p[S][t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, p_c)));
-            const float* vrow = V + (int64_t)idx * ld;
+            idxM[t] = __builtin_amdgcn_ds_bpermute(src, idx_c);
+            wM[t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w_c)));
+            pM[t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, p_c)));
+        }
+    }
+
+    // request the factor rows of group g into ring slot S (compile time); fetch_meta(g) must have run,
+    // and groups are requested in increasing order, so the metadata of g + 1 is fetched on the way out.
+    template <int S>
+    __device__ __forceinline__ void load_group(int g, const float* __restrict__ V, int ld, int r, int q, int last_col) {
+#pragma unroll
+        for (int t = 0; t < GS; ++t) {
+            w[S][t] = wM[t];
+            p[S][t] = pM[t];
+            const float* vrow = V + (int64_t)idxM[t] * ld;
 #pragma unroll
             for (int fb = 0; fb < NFB - 1; ++fb) fr[S][t][fb] = vrow[16 * fb + r];
             fr[S][t][NFB - 1] = vrow[last_col];                                      // masked by the consumer
         }
+        fetch_meta(g + 1, q);
     }
 };
