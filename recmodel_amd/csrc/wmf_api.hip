@@ -163,13 +163,43 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, wmf_plan** out) {
     for (int b = 0; b < WMF_NBINS; ++b) start[b + 1] = start[b] + p->count[b];
     int64_t fill[WMF_NBINS];
     for (int b = 0; b < WMF_NBINS; ++b) fill[b] = start[b];
-    for (int64_t r = 0; r < n; ++r) order[(size_t)fill[bin_of(indptr[r + 1] - indptr[r], f)]++] = (int32_t)r;
+    // within the MFMA bin: ordinary rows first, rows with more than WMF_HEAVY_T entries last (split into segments)
+    std::vector<int32_t> heavy;
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t d = indptr[r + 1] - indptr[r];
+        const int b = bin_of(d, f);
+        if (b == WMF_BIN_MFMA && d > WMF_HEAVY_T) { heavy.push_back((int32_t)r); continue; }
+        order[(size_t)fill[b]++] = (int32_t)r;
+    }
+    std::vector<int64_t> seg_lo;
+    std::vector<int32_t> seg_d, seg_first(1, 0);
+    for (int32_t r : heavy) {
+        order[(size_t)fill[WMF_BIN_MFMA]++] = r;
+        const int64_t d = indptr[r + 1] - indptr[r];
+        for (int64_t off = 0; off < d; off += WMF_SEG) {
+            seg_lo.push_back(indptr[r] + off);
+            seg_d.push_back((int32_t)(d - off < WMF_SEG ? d - off : WMF_SEG));
+        }
+        seg_first.push_back((int32_t)seg_lo.size());
+    }
+    p->heavy_count = (int64_t)heavy.size();
+    p->seg_total = (int64_t)seg_lo.size();
     const size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(int32_t);
     hipError_t e = hipMalloc((void**)&p->rows_all, bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&p->fallback_rows, bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&p->fallback_count, 256);
     if (e == hipSuccess && n > 0) e = hipMemcpy(p->rows_all, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(p->fallback_count, 0, 256);
+    if (e == hipSuccess && p->heavy_count > 0) {
+        const int64_t nfb = (f + 15) / 16, nt = nfb * (nfb + 1) / 2 + nfb;
+        e = hipMalloc((void**)&p->seg_lo, seg_lo.size() * sizeof(int64_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&p->seg_d, seg_d.size() * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&p->seg_first, seg_first.size() * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&p->partial, (size_t)p->seg_total * nt * 256 * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(p->seg_lo, seg_lo.data(), seg_lo.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->seg_d, seg_d.data(), seg_d.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->seg_first, seg_first.data(), seg_first.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         wmf_set_error("wmf_plan_create: %s", hipGetErrorString(e));
         wmf_plan_destroy(p);
@@ -186,6 +216,10 @@ void wmf_plan_destroy(wmf_plan* p) {
     if (p->fallback_rows) (void)hipFree(p->fallback_rows);
     if (p->fallback_count) (void)hipFree(p->fallback_count);
     if (p->w_eff) (void)hipFree(p->w_eff);
+    if (p->seg_lo) (void)hipFree(p->seg_lo);
+    if (p->seg_d) (void)hipFree(p->seg_d);
+    if (p->seg_first) (void)hipFree(p->seg_first);
+    if (p->partial) (void)hipFree(p->partial);
     delete p;
 }
 

@@ -30,14 +30,20 @@ __device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for
     return bi * (NFB + 1) - (bi * (bi - 1)) / 2 + (bj - bi);
 }
 
-template <int NFB>
+// MODE 0: one wave per row (accumulate + eliminate).
+// Rows with more than WMF_HEAVY_T entries are split (power-law degrees):
+// MODE 1: one wave per SEGMENT of such a row: accumulate its WMF_SEG entries, store the partial tiles;
+// MODE 2: one wave per heavy row: add the partial tiles of its segments in order, then eliminate.
+template <int NFB, int MODE>
 __global__ __launch_bounds__(64, (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1))) void solve_directw_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                               const float* __restrict__ V, const float* __restrict__ biasv,
                                                               const int64_t* __restrict__ indptr,
                                                               const int32_t* __restrict__ indices,
                                                               const float* __restrict__ vals, int f, int ld,
                                                               float* __restrict__ g, int32_t* __restrict__ fb_rows,
-                                                              int32_t* __restrict__ fb_count, int dbg) {
+                                                              int32_t* __restrict__ fb_count, int dbg,
+                                                              const int64_t* __restrict__ seg_lo, const int32_t* __restrict__ seg_d,
+                                                              const int32_t* __restrict__ seg_first, float* __restrict__ partial) {
     constexpr int NT = NFB * (NFB + 1) / 2 + NFB;
     constexpr int GS = 2;                                        // MFMA k-steps (4 entries each) per pipelined group
     __shared__ __attribute__((aligned(16))) float Pan1[(NFB + 1) * 320];     // original tiles of block row p
@@ -58,8 +64,13 @@ __global__ __launch_bounds__(64, (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1))) void solve
     int u = 0, d = 0;
     int64_t lo = 0;
     int64_t it = blockIdx.x;
-    if (it < count) { u = rows[it]; lo = indptr[u]; d = (int)(indptr[u + 1] - lo); }
+    auto item = [&](int64_t i, int& u_, int64_t& lo_, int& d_) {   // work item i: a row (MODE 0, 2) or a segment (MODE 1)
+        if constexpr (MODE == 1) { u_ = 0; lo_ = seg_lo[i]; d_ = seg_d[i]; }
+        else { u_ = rows[i]; lo_ = indptr[u_]; d_ = (int)(indptr[u_ + 1] - lo_); }
+    };
+    if (it < count) item(it, u, lo, d);
     auto prime = [&](int64_t lo_, int d_) {
+        if constexpr (MODE == 2) return;
         st.load_block(0, lo_, d_, indices, vals, lane, 0);
         st.load_block(1, lo_, d_, indices, vals, lane, 1);
         st.fetch_meta(0, q);
@@ -70,11 +81,11 @@ __global__ __launch_bounds__(64, (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1))) void solve
     if (it < count) prime(lo, d);
 
     for (; it < count; it += gridDim.x) {
-        const int ngroups = (d + Stream::EPG - 1) / Stream::EPG;
+        const int ngroups = (MODE == 2) ? 0 : (d + Stream::EPG - 1) / Stream::EPG;
         const int64_t itn = it + gridDim.x;
         int un = 0, dn = 0;
         int64_t lon = 0;
-        if (itn < count) { un = rows[itn]; lon = indptr[un]; dn = (int)(indptr[un + 1] - lon); }
+        if (itn < count) item(itn, un, lon, dn);
 
         f32x4 acc[NT];
 #pragma unroll
@@ -129,6 +140,24 @@ __global__ __launch_bounds__(64, (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1))) void solve
             }
         }
         if (itn < count) prime(lon, dn);                         // next row's first loads fly during the elimination
+        if constexpr (MODE == 1) {                               // partial tiles of this segment: [tile][reg][lane]
+            float* out = partial + it * (int64_t)(NT * 256);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) out[(t * 4 + reg) * 64 + lane] = acc[t][reg];
+            u = un; lo = lon; d = dn;
+            continue;
+        }
+        if constexpr (MODE == 2) {                               // sum the segments of heavy row `it` in a fixed order
+            for (int sgm = seg_first[it]; sgm < seg_first[it + 1]; ++sgm) {
+                const float* in = partial + sgm * (int64_t)(NT * 256);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) acc[t][reg] += in[(t * 4 + reg) * 64 + lane];
+            }
+        }
 
         // ---- C: block elimination, everything in registers except the two panel buffers
         bool ok = true;
@@ -211,23 +240,34 @@ __global__ __launch_bounds__(64, (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1))) void solve
 }
 
 template <int NFB>
-static void launch_directw_nfb(const int32_t* rows, int64_t count, const float* V, const float* biasv,
-                               const int64_t* indptr, const int32_t* indices, const float* vals, int f, int ld, float* g,
-                               int32_t* fb_rows, int32_t* fb_count, int dbg, hipStream_t st) {
+static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
+                               const int32_t* indices, const float* vals, int f, int ld, float* g, int dbg, hipStream_t st) {
     constexpr int waves_per_cu = 4 * (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1));
-    int64_t grid = 256 * waves_per_cu * 3;                       // resident waves, three rounds queued
-    if (grid > count) grid = count;
-    hipLaunchKernelGGL((solve_directw_kernel<NFB>), dim3((unsigned)grid), dim3(64), 0, st, rows, count, V, biasv, indptr,
-                       indices, vals, f, ld, g, fb_rows, fb_count, dbg);
+    const int64_t cap = 256 * waves_per_cu * 3;                  // resident waves, three rounds queued
+    const int32_t* rows = pl->rows[WMF_BIN_MFMA];
+    const int64_t normal = pl->count[WMF_BIN_MFMA] - pl->heavy_count;
+    if (normal > 0)
+        hipLaunchKernelGGL((solve_directw_kernel<NFB, 0>), dim3((unsigned)(normal < cap ? normal : cap)), dim3(64), 0, st, rows,
+                           normal, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
+                           nullptr, nullptr, nullptr, nullptr);
+    if (pl->heavy_count > 0) {
+        const int64_t nseg = pl->seg_total;
+        hipLaunchKernelGGL((solve_directw_kernel<NFB, 1>), dim3((unsigned)(nseg < cap ? nseg : cap)), dim3(64), 0, st, rows, nseg,
+                           V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg, pl->seg_lo,
+                           pl->seg_d, pl->seg_first, pl->partial);
+        const int64_t nh = pl->heavy_count;
+        hipLaunchKernelGGL((solve_directw_kernel<NFB, 2>), dim3((unsigned)(nh < cap ? nh : cap)), dim3(64), 0, st, rows + normal,
+                           nh, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg, pl->seg_lo,
+                           pl->seg_d, pl->seg_first, pl->partial);
+    }
 }
 
-int wmf_launch_directw(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
-                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
-                       int32_t* fb_count, hipStream_t st) {
-    if (count <= 0) return 0;
+int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
+                       const int32_t* indices, const float* vals, int f, int ld, float* g, hipStream_t st) {
+    if (pl->count[WMF_BIN_MFMA] <= 0) return 0;
     const int dbg = wmf_debug_flags;
     switch ((f + 15) / 16) {
-#define C_(N) case N: launch_directw_nfb<N>(rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, st); break;
+#define C_(N) case N: launch_directw_nfb<N>(pl, V, biasv, indptr, indices, vals, f, ld, g, dbg, st); break;
         C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9)
 #undef C_
         default: return -1;

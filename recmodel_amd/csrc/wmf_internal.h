@@ -5,6 +5,8 @@
 
 #define WMF_GRAM_MAX_WAVES 4096
 #define WMF_EVAL_MAX_BLOCKS 2048
+#define WMF_HEAVY_T 4096      /* rows with more stored entries are accumulated by several waves ... */
+#define WMF_SEG 2048          /* ... in segments of this many entries */
 
 // row-degree bins of a plan
 enum { WMF_BIN_LOW16 = 0, WMF_BIN_LOW32 = 1, WMF_BIN_MFMA = 2, WMF_BIN_GENERAL = 3, WMF_NBINS = 4 };
@@ -19,6 +21,12 @@ struct wmf_plan {
     int32_t* fallback_rows;    // device: n slots, rows bounced to the general kernel at run time
     int32_t* fallback_count;   // device: 1 counter
     float* w_eff;              // device: nnz effective weights (values - bias[indices]), allocated on first biased solve
+    // rows of the MFMA bin with more than WMF_HEAVY_T entries sit at the end of that bin and are split into segments
+    int64_t heavy_count, seg_total;
+    int64_t* seg_lo;           // device: first entry of each segment
+    int32_t* seg_d;            // device: entries in each segment
+    int32_t* seg_first;        // device: heavy_count + 1 prefix of segment counts
+    float* partial;            // device: seg_total x (tiles x 256) partial accumulators
 };
 
 int wmf_gram_max_waves(int f);
@@ -37,9 +45,8 @@ int wmf_direct_supported(int f);
 int wmf_launch_direct(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
                       int32_t* fb_count, hipStream_t st);
-int wmf_launch_directw(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
-                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
-                       int32_t* fb_count, hipStream_t st);
+int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
+                       const int32_t* indices, const float* vals, int f, int ld, float* g, hipStream_t st);
 int wmf_launch_direct64(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                         const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
                         int32_t* fb_count, hipStream_t st);

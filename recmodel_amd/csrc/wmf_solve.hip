@@ -500,10 +500,16 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
         // One wave per row with the whole system in MFMA accumulator registers (wmf_directw.hip).  Debug flags
         // select the two earlier designs, kept for A/B timing: 16 = workgroup per row (wmf_direct.hip),
         // 128 = one wave per row with an LDS image of the matrix (wmf_direct64.hip, f <= 64 only).
-        auto fn = (wmf_debug_flags & 16) ? wmf_launch_direct
-                  : ((f <= 64 && (wmf_debug_flags & 128)) ? wmf_launch_direct64 : wmf_launch_directw);
-        if (fn(pl->rows[WMF_BIN_MFMA], pl->count[WMF_BIN_MFMA], V, biasv, indptr, indices, vals, f, ld, g,
-               pl->fallback_rows, pl->fallback_count, st)) return -1;
+        int rc;
+        if (wmf_debug_flags & 16)
+            rc = wmf_launch_direct(pl->rows[WMF_BIN_MFMA], pl->count[WMF_BIN_MFMA], V, biasv, indptr, indices, vals, f, ld, g,
+                                   pl->fallback_rows, pl->fallback_count, st);
+        else if (f <= 64 && (wmf_debug_flags & 128))
+            rc = wmf_launch_direct64(pl->rows[WMF_BIN_MFMA], pl->count[WMF_BIN_MFMA], V, biasv, indptr, indices, vals, f, ld, g,
+                                     pl->fallback_rows, pl->fallback_count, st);
+        else
+            rc = wmf_launch_directw(pl, V, biasv, indptr, indices, vals, f, ld, g, st);
+        if (rc) return -1;
     }
     if (pl->count[WMF_BIN_GENERAL] > 0) {
         if (!general_ok) return -1;

@@ -300,3 +300,24 @@ def test_device_building_blocks_individually():
     ws = torch.empty(int(lib.wmf_gram_workspace_bytes(f)), dtype=torch.uint8, device="cuda")
     _lib.check(lib.wmf_factorize(_ptr(G), f, ld, 0.1, _ptr(Ww), _ptr(Wu), _ptr(info), _ptr(ws), _stream()))
     assert int(info[0]) == 1 and float(Ww.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("k,bias", [(32, False), (128, True)])
+def test_very_heavy_rows_are_split_into_segments(WMF, k, bias):
+    """Rows with more than 4096 stored entries (power-law heads) are accumulated by
+    several waves in 2048-entry segments and combined in a fixed order."""
+    rng = np.random.default_rng(9)
+    n, m_items = 60, 13000
+    degs = [5000, 9000, 13000, 4096, 4097] + [int(x) for x in rng.integers(1, 200, n - 5)]
+    indptr = np.concatenate([[0], np.cumsum(degs)])
+    indices = np.concatenate([np.sort(rng.choice(m_items, d, replace=False)) for d in degs]).astype(np.int32)
+    data = (10 * np.log(1 + rng.integers(1, 6, indptr[-1]))).astype(np.float32)
+    C = sp.csr_matrix((data, indices, indptr), shape=(n, m_items))
+    model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=bias)
+    step_o = orc.recompute_factors_bias if bias else orc.recompute_factors
+    step_g = model.recompute_factors_bias if bias else model.recompute_factors
+    want = step_o(model.items, as_f64(C), 0.1, out_dtype="float64")
+    got = step_g(model.items, C, 0.1)
+    rel, _ = worst_row(got, want)
+    assert fro(got, want) <= HALF_FRO and rel <= HALF_ROW, (fro(got, want), rel)
+    assert np.array_equal(got, step_g(model.items, C, 0.1))          # fixed combination order: bitwise reproducible
