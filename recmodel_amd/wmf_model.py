@@ -244,6 +244,11 @@ class WMF(RecModel):
             if count_improvement >= stopping_rounds:
                 break
         self._pull(eng)
+        if cores > 1:
+            # dtype quirk of the reference: its Pool variants (wmf_model.py:242-265) stack float64 row results
+            # without the cast back to self.dtype.  Values are the float32 results, widened.
+            self.users, self.items = self.users.astype(np.float64), self.items.astype(np.float64)
+            self._synced = (id(self.users), id(self.items))
         if verbose > 0:
             print("Training was completed.")
         if verbose > 1:

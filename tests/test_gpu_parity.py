@@ -187,6 +187,7 @@ def test_full_training_vs_oracle(WMF):
     for bias in (False, True):
         model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=bias)
         last = model.train(utility_mat=counts, iterations=3, eval_mat=counts, count_mat=counts, cores=2, stopping_rounds=5)
+        assert model.users.dtype == np.float64 and model.items.dtype == np.float64    # the reference's cores > 1 quirk
         r_last, r_hist, r_users, r_items = orc.train(m_items, n, k, 0.1, counts, 3, counts, count_mat=counts,
                                                      weighted=True, bias=bias, stopping_rounds=5)
         assert last == r_last == 2
