@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwmf_hip.so")
+LIB_PATH = os.environ.get("WMF_HIP_LIB", os.path.join(_HERE, "libwmf_hip.so"))   # override: kernel tuning experiments
 
 WMF_OK, WMF_EINVAL, WMF_EHIP, WMF_ENOMEM, WMF_ENUMERIC = 0, -1, -2, -3, -4
 WMF_PROF_SLOTS = 12

@@ -64,6 +64,18 @@ __device__ __forceinline__ float rlw(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+// Value of 16-lane row group KQ (lanes 16 KQ .. 16 KQ + 15) copied to all four row groups, lane for lane,
+// with two VALU swaps and no LDS round trip (v_permlane32_swap: lanes 32-63 of a <-> lanes 0-31 of b;
+// v_permlane16_swap: odd rows of a <-> even rows of b).
+template <int KQ>
+__device__ __forceinline__ float wmf_bcast_rowgroup(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    const auto s = __builtin_amdgcn_permlane32_swap(x, x, false, false);      // {g0 g1 g0 g1}, {g2 g3 g2 g3}
+    const int h = (KQ < 2) ? s[0] : s[1];
+    const auto t = __builtin_amdgcn_permlane16_swap(h, h, false, false);      // {ga ga ga ga}, {gb gb gb gb}
+    return __builtin_bit_cast(float, (KQ & 1) ? t[1] : t[0]);
+}
+
 // In-place Gauss-Jordan inverse of a symmetric positive definite 16 x 16 tile held row-distributed:
 // lane (r, q) has A[r][4q + reg] in a[reg].  Step K: column K becomes e_K first, then every row gets
 // row_i += nf_i * row_K with nf = -A[i][K]/piv (rows i != K) or 1/piv - 1 (row K).
@@ -74,7 +86,7 @@ __device__ __forceinline__ void gj_inv_step(f32x4& a, const int (&baddr)[4], int
     const float piv = rlw(akr, K + 16 * kq);
     if (!(piv > 1e-20f)) ok = false;
     const float inv = __builtin_amdgcn_rcpf(piv);
-    const float fk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(baddr[kq], __builtin_bit_cast(int, akr)));
+    const float fk = wmf_bcast_rowgroup<kq>(akr);     // A[r][K] sits in lane (r, kq): VALU swaps instead of a ds_bpermute round trip
     if (q == kq) a[kr] = (r == K) ? 1.f : 0.f;
     const float nf = (r == K) ? inv - 1.f : -fk * inv;
     float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];

@@ -37,8 +37,6 @@ __global__ __launch_bounds__(64, 3) void solve_direct64_kernel(const int32_t* __
     __shared__ __attribute__((aligned(16))) float Bm[FP * LDB];
     const int lane = threadIdx.x;
     const int r = lane & 15, q = lane >> 4;
-    const int last_col = min(16 * (NFB - 1) + r, ld - 1);       // only the last feature block can run past ld
-    const float last_mask = (16 * (NFB - 1) + r < ld) ? 1.f : 0.f;
 
     // Row pipeline (wmf_stream.h): factor rows are requested DEPTH groups ahead; the first loads of the
     // NEXT row are requested before this row's factorisation starts, so their latency hides behind it.
@@ -53,9 +51,9 @@ __global__ __launch_bounds__(64, 3) void solve_direct64_kernel(const int32_t* __
         st.load_block(0, lo_, d_, indices, vals, lane, 0);
         st.load_block(1, lo_, d_, indices, vals, lane, 1);
         st.fetch_meta(0, q);
-        st.template load_group<0>(0, V, ld, r, q, last_col);
-        st.template load_group<1>(1, V, ld, r, q, last_col);
-        st.template load_group<2>(2, V, ld, r, q, last_col);
+        st.template load_group<0>(0, V, ld, r, q);
+        st.template load_group<1>(1, V, ld, r, q);
+        st.template load_group<2>(2, V, ld, r, q);
     };
     if (it < count) prime(lo, d);
 
@@ -81,7 +79,7 @@ __global__ __launch_bounds__(64, 3) void solve_direct64_kernel(const int32_t* __
 #pragma unroll
                 for (int t = 0; t < GS; ++t) {
                     float fw[NFB];
-                    st.fr[S][t][NFB - 1] *= last_mask;
+                    st.template mask_tail<S>(t, ld, r);
 #pragma unroll
                     for (int fb = 0; fb < NFB; ++fb) { fw[fb] = st.fr[S][t][fb] * st.w[S][t]; racc[fb] += st.fr[S][t][fb] * st.p[S][t]; }
                     int tt = 0;
@@ -97,7 +95,7 @@ __global__ __launch_bounds__(64, 3) void solve_direct64_kernel(const int32_t* __
                     const int c = next / Stream::GPB;
                     st.load_block(c + 1, lo, d, indices, vals, lane, (c + 1) & 1);
                 }
-                st.template load_group<S>(next, V, ld, r, q, last_col);
+                st.template load_group<S>(next, V, ld, r, q);
             }
         };
         for (int G0 = 0; G0 < ngroups; G0 += DEPTH) {
@@ -204,8 +202,9 @@ __global__ __launch_bounds__(64, 3) void solve_direct64_kernel(const int32_t* __
         }
         if (!ok) {                                               // not positive definite: the pivoted LU kernel redoes the row
             if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;
-        } else if (lane < ld) {
-            g[(int64_t)u * ld + lane] = (lane < f) ? y : 0.f;
+        } else {
+            const int c = Stream::real_col(lane >> 4, lane & 15);        // undo the feature permutation of the row stream
+            if (lane < FP && c < ld) g[(int64_t)u * ld + c] = (c < f) ? y : 0.f;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

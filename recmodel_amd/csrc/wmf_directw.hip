@@ -25,6 +25,24 @@
 
 #include <utility>
 
+// Tunables per factor width (measured on MI355X, tools/kernel_lab.py): k-steps per pipelined group, ring
+// depth, waves per SIMD the register budget is cut for.
+#ifndef WMF_DW_GS
+#define WMF_DW_GS 2
+#endif
+#ifndef WMF_DW_DEPTH
+#define WMF_DW_DEPTH 3
+#endif
+#ifndef WMF_DW_OCC4
+#define WMF_DW_OCC4 3
+#endif
+template <int NFB>
+struct DwCfg {
+    static constexpr int GS = (NFB <= 4) ? WMF_DW_GS : 2;
+    static constexpr int DEPTH = (NFB <= 4) ? WMF_DW_DEPTH : 3;
+    static constexpr int OCC = NFB <= 4 ? WMF_DW_OCC4 : (NFB <= 6 ? 2 : 1);      // waves per SIMD
+};
+
 template <int NFB>
 __device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for bj = bi .. NFB"
     return bi * (NFB + 1) - (bi * (bi - 1)) / 2 + (bj - bi);
@@ -35,7 +53,7 @@ __device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for
 // MODE 1: one wave per SEGMENT of such a row: accumulate its WMF_SEG entries, store the partial tiles;
 // MODE 2: one wave per heavy row: add the partial tiles of its segments in order, then eliminate.
 template <int NFB, int MODE>
-__global__ __launch_bounds__(64, (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1))) void solve_directw_kernel(const int32_t* __restrict__ rows, int64_t count,
+__global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                               const float* __restrict__ V, const float* __restrict__ biasv,
                                                               const int64_t* __restrict__ indptr,
                                                               const int32_t* __restrict__ indices,
@@ -45,20 +63,18 @@ __global__ __launch_bounds__(64, (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1))) void solve
                                                               const int64_t* __restrict__ seg_lo, const int32_t* __restrict__ seg_d,
                                                               const int32_t* __restrict__ seg_first, float* __restrict__ partial) {
     constexpr int NT = NFB * (NFB + 1) / 2 + NFB;
-    constexpr int GS = 2;                                        // MFMA k-steps (4 entries each) per pipelined group
+    constexpr int GS = DwCfg<NFB>::GS;                           // MFMA k-steps (4 entries each) per pipelined group
     __shared__ __attribute__((aligned(16))) float Pan1[(NFB + 1) * 320];     // original tiles of block row p
     __shared__ __attribute__((aligned(16))) float Pan2[(NFB + 1) * 320];     // W tiles of block row p
     const int lane = threadIdx.x;
     const int r = lane & 15, q = lane >> 4;
-    const int last_col = min(16 * (NFB - 1) + r, ld - 1);       // only the last feature block can run past ld
-    const float last_mask = (16 * (NFB - 1) + r < ld) ? 1.f : 0.f;
     int baddr[4];
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) baddr[kq] = (r + 16 * kq) * 4;
 
     // Row pipeline (wmf_stream.h): factor rows are requested DEPTH groups ahead; the next row's first loads
     // are requested before this row's elimination starts.
-    constexpr int DEPTH = 3;
+    constexpr int DEPTH = DwCfg<NFB>::DEPTH;
     using Stream = WmfRowStream<NFB, GS, DEPTH>;
     Stream st;
     int u = 0, d = 0;
@@ -74,9 +90,9 @@ __global__ __launch_bounds__(64, (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1))) void solve
         st.load_block(0, lo_, d_, indices, vals, lane, 0);
         st.load_block(1, lo_, d_, indices, vals, lane, 1);
         st.fetch_meta(0, q);
-        st.template load_group<0>(0, V, ld, r, q, last_col);
-        st.template load_group<1>(1, V, ld, r, q, last_col);
-        st.template load_group<2>(2, V, ld, r, q, last_col);
+        [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
+            (st.template load_group<Ss>(Ss, V, ld, r, q), ...);
+        }(std::make_integer_sequence<int, DEPTH>{});
     };
     if (it < count) prime(lo, d);
 
@@ -102,7 +118,7 @@ __global__ __launch_bounds__(64, (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1))) void solve
 #pragma unroll
                 for (int t = 0; t < GS; ++t) {
                     float fw[NFB];
-                    st.fr[S][t][NFB - 1] *= last_mask;
+                    st.template mask_tail<S>(t, ld, r);
 #pragma unroll
                     for (int fb = 0; fb < NFB; ++fb) { fw[fb] = st.fr[S][t][fb] * st.w[S][t]; racc[fb] += st.fr[S][t][fb] * st.p[S][t]; }
                     int tt = 0;
@@ -120,13 +136,13 @@ __global__ __launch_bounds__(64, (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1))) void solve
                     const int c = next / Stream::GPB;
                     st.load_block(c + 1, lo, d, indices, vals, lane, (c + 1) & 1);
                 }
-                st.template load_group<S>(next, V, ld, r, q, last_col);
+                st.template load_group<S>(next, V, ld, r, q);
             }
         };
         for (int G0 = 0; G0 < ngroups; G0 += DEPTH) {
-            step(std::integral_constant<int, 0>{}, G0);
-            step(std::integral_constant<int, 1>{}, G0 + 1);
-            step(std::integral_constant<int, 2>{}, G0 + 2);
+            [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
+                (step(std::integral_constant<int, Ss>{}, G0 + Ss), ...);
+            }(std::make_integer_sequence<int, DEPTH>{});
         }
         // rhs[16 fb + r] on every lane (r, *), then into column 0 of the rhs tiles: lane (0, q) needs rows 4q + reg
 #pragma unroll
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(64, (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1))) void solve
         } else if (q == 0) {
 #pragma unroll
             for (int p = 0; p < NFB; ++p) {
-                const int c = 16 * p + r;
+                const int c = Stream::real_col(p, r);            // undo the feature permutation of the row stream
                 if (c < ld) g[(int64_t)u * ld + c] = (c < f) ? gb[p] : 0.f;
             }
         }
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(64, (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1))) void solve
 template <int NFB>
 static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
                                const int32_t* indices, const float* vals, int f, int ld, float* g, int dbg, hipStream_t st) {
-    constexpr int waves_per_cu = 4 * (NFB <= 4 ? 3 : (NFB <= 6 ? 2 : 1));
+    constexpr int waves_per_cu = 4 * DwCfg<NFB>::OCC;
     const int64_t cap = 256 * waves_per_cu * 3;                  // resident waves, three rounds queued
     const int32_t* rows = pl->rows[WMF_BIN_MFMA];
     const int64_t normal = pl->count[WMF_BIN_MFMA] - pl->heavy_count;

@@ -2,7 +2,14 @@
 // one-wave-per-row direct kernels.
 //
 // Lane (r = l & 15, q = l >> 4).  MFMA k-step t of group g consumes the four entries 4 GS g + 4 t + q
-// (q = 0..3 are the four k slots); its A/B operand for feature block fb is V[idx][16 fb + r].
+// (q = 0..3 are the four k slots); the A/B operand of "virtual feature block" vb is one feature of row idx.
+// FEATURE PERMUTATION: the f x f system is built and solved in a permuted feature order so that the
+// gather can use 16-byte loads: lane r takes the pieces V[idx][4 (r + 16 j) .. +3], j < J = NFB / 4, and
+// register e of piece j is virtual block 4 j + e (real feature 64 j + 4 r + e); the NFB % 4 remaining
+// blocks are dword loads of feature 64 J + 16 rr + r.  One dwordx4 instruction then moves four whole
+// 256-byte row segments instead of four 64-byte ones (4x fewer vector-memory instructions; the dword
+// form was bound by the address/tag pipeline, not by HBM).  The solve is invariant under the
+// permutation; only the final store maps virtual (block, lane) back to the real column (real_col()).
 //   * entry metadata travels in BLOCKS of 64 entries: lane l keeps (index, weight, p = weight + 1) of entry
 //     64 c + l, two blocks resident; a group picks its four entries out of the block with ds_bpermute.
 //     Entries past the row's end are clamped to the last real entry and get weight 0 and p 0, which
@@ -16,6 +23,7 @@
 
 template <int NFB, int GS, int D>
 struct WmfRowStream {
+    static constexpr int J = NFB / 4, R = NFB % 4;  // 16-byte pieces and dword blocks per lane and entry
     static constexpr int EPG = 4 * GS;            // entries per group
     static constexpr int GPB = 64 / EPG;          // groups per 64-entry block
     float fr[D][GS][NFB];                         // factor-row operands
@@ -56,16 +64,42 @@ struct WmfRowStream {
     // request the factor rows of group g into ring slot S (compile time); fetch_meta(g) must have run,
     // and groups are requested in increasing order, so the metadata of g + 1 is fetched on the way out.
     template <int S>
-    __device__ __forceinline__ void load_group(int g, const float* __restrict__ V, int ld, int r, int q, int last_col) {
+    __device__ __forceinline__ void load_group(int g, const float* __restrict__ V, int ld, int r, int q) {
+        const int nch = ld >> 2;
 #pragma unroll
         for (int t = 0; t < GS; ++t) {
             w[S][t] = wM[t];
             p[S][t] = pM[t];
             const float* vrow = V + (int64_t)idxM[t] * ld;
 #pragma unroll
-            for (int fb = 0; fb < NFB - 1; ++fb) fr[S][t][fb] = vrow[16 * fb + r];
-            fr[S][t][NFB - 1] = vrow[last_col];                                      // masked by the consumer
+            for (int j = 0; j < J; ++j) {
+                const int c = (R == 0 && j == J - 1) ? min(r + 16 * j, nch - 1) : r + 16 * j;   // only the last piece can run past the row
+                const float4 v = reinterpret_cast<const float4*>(vrow)[c];
+                fr[S][t][4 * j] = v.x; fr[S][t][4 * j + 1] = v.y; fr[S][t][4 * j + 2] = v.z; fr[S][t][4 * j + 3] = v.w;
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int col = 64 * J + 16 * rr + r;
+                fr[S][t][4 * J + rr] = vrow[rr == R - 1 ? min(col, ld - 1) : col];
+            }
         }
         fetch_meta(g + 1, q);
+    }
+
+    // consumer side: zero the features that lie beyond the row (their loads were clamped)
+    template <int S>
+    __device__ __forceinline__ void mask_tail(int t, int ld, int r) {
+        if constexpr (R == 0) {
+            const float m = (4 * (r + 16 * (J - 1)) < ld) ? 1.f : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fr[S][t][4 * (J - 1) + e] *= m;
+        } else {
+            fr[S][t][NFB - 1] *= (64 * J + 16 * (R - 1) + r < ld) ? 1.f : 0.f;
+        }
+    }
+
+    // real column of virtual block vb on lane r
+    static __device__ __forceinline__ int real_col(int vb, int r) {
+        return vb < 4 * J ? 64 * (vb >> 2) + 4 * r + (vb & 3) : 64 * J + 16 * (vb - 4 * J) + r;
     }
 };

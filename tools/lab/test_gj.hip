@@ -5,27 +5,6 @@
 #include <vector>
 #include <utility>
 #include "../../recmodel_amd/csrc/wmf_common.h"
-__device__ __forceinline__ float rlw(float v, int lane) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
-template <int K>
-__device__ __forceinline__ void gj_inv_step(f32x4& a, const int (&baddr)[4], int r, int q, bool& ok) {
-    constexpr int kq = K >> 2, kr = K & 3;
-    const float akr = a[kr];     // copy first: __builtin_bit_cast applied to the vector-element lvalue itself reads element 0
-    const float piv = rlw(akr, K + 16 * kq);
-    if (!(piv > 1e-20f)) ok = false;
-    const float inv = __builtin_amdgcn_rcpf(piv);
-    const float fk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(baddr[kq], __builtin_bit_cast(int, akr)));
-    if (q == kq) a[kr] = (r == K) ? 1.f : 0.f;
-    const float nf = (r == K) ? inv - 1.f : -fk * inv;
-    float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
-    fmac_bcast4_self<K>(a0, a1, a2, a3, nf);
-    a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3;
-}
-template <int... Ks>
-__device__ __forceinline__ void gj_inv_sweep(f32x4& a, const int (&baddr)[4], int r, int q, bool& ok, std::integer_sequence<int, Ks...>) {
-    (gj_inv_step<Ks>(a, baddr, r, q, ok), ...);
-}
 __global__ void k(const float* A, float* X) {
     int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
     f32x4 a;
