@@ -14,7 +14,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int CTRL>
 __device__ __forceinline__ float wmf_dpp(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
 // Sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15); every lane of the row gets the total.
@@ -24,6 +24,21 @@ __device__ __forceinline__ float wmf_row16_sum(float v) {
     v += wmf_dpp<0x141>(v);   // row_half_mirror
     v += wmf_dpp<0x140>(v);   // row_mirror
     return v;
+}
+
+// Four independent row sums as 16 v_add_f32_dpp (hipcc leaves a v_mov_dpp + add pair per stage).  The four
+// values are interleaved so that three instructions separate a register's write from its DPP read (the
+// hazard needs two wait states); the leading s_nop covers the first stage.
+__device__ __forceinline__ void wmf_row16_sum4(float& a, float& b, float& c, float& d) {
+#define WMF_STAGE(ctrl)                                                  \
+    "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile("s_nop 1\n\t" WMF_STAGE("quad_perm:[1,0,3,2]") WMF_STAGE("quad_perm:[2,3,0,1]")
+                 WMF_STAGE("row_half_mirror") WMF_STAGE("row_mirror")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef WMF_STAGE
 }
 
 __device__ __forceinline__ double wmf_wave_sum_f64(double v) {

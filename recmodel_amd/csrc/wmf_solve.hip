@@ -101,8 +101,11 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
     const int r = lane & 15, q = lane >> 4;
     const int nch = ld >> 2;
 
-    // All loads are unconditional (clamped to a stored entry) and their values are MULTIPLIED by a
-    // 0/1 mask: under a per-lane select hipcc sinks the load into a branch and waits for each in turn.
+    // All loads are unconditional and clamped to a stored entry (under a per-lane select hipcc sinks the load
+    // into a branch and waits for each in turn).  Slots j >= d read the factor row of entry 0 -- real, finite
+    // data -- with weight 0 and p 0: their row of I + D S is an identity row and their c_j is exactly 0, so
+    // they drop out of every product without masking the 16 x NCH gathered values.  Only the last piece can
+    // run past the row's ld features; it is clamped and multiplied by 0.
     float w[NSETS], p[NSETS];
     float4 x[NSETS][NCH];
     bool neg = false;
@@ -120,15 +123,12 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
         wj *= am;
         if (!(wj >= 0.f)) neg = true;               // negative or NaN weight: needs pivoting
         w[s] = wj;
-        p[s] = wj + 1.f;
+        p[s] = wj + am;
         const float4* vrow = Vq + (int64_t)idx * nch;
 #pragma unroll
-        for (int t = 0; t < NCH; ++t) {
-            // only the last piece index can run past the row (nch > 4 (NCH - 1) by construction)
-            const float4 v = (t < NCH - 1) ? vrow[4 * t] : (vrow - q)[last_c];
-            const float m = (t < NCH - 1) ? am : am * last_m;
-            x[s][t] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
-        }
+        for (int t = 0; t < NCH - 1; ++t) x[s][t] = vrow[4 * t];
+        const float4 v = (vrow - q)[last_c];
+        x[s][NCH - 1] = make_float4(v.x * last_m, v.y * last_m, v.z * last_m, v.w * last_m);
     }
     if (__any(neg)) {                               // wave-uniform: bounce the row to the LU kernel
         if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;
@@ -141,21 +141,35 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
     // ---- S blocks by MFMA: Sb[s][c][reg] = S[row r + 16 s][col 16 c + 4 q + reg].  acc layout is D[4q + reg][r];
     //      S symmetric, so tile(a = x[c], b = x[s]) = S[set c row 4q+reg][set s row r] = S[set s row r][set c row 4q+reg].
     float Sb[NSETS][NSETS][4];
+    {
+        // one accumulator per tile; the NSETS^2 tiles are interleaved so that dependent MFMAs are NSETS^2 - 1
+        // (NSETS = 1: 0, hence two chains there) instructions apart
+        f32x4 acc[NSETS][NSETS], acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < NSETS; ++s) {
+        for (int s = 0; s < NSETS; ++s)
 #pragma unroll
-        for (int c = 0; c < NSETS; ++c) {
-            f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < NSETS; ++c) acc[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < NCH; ++t) {
-                a0 = WMF_MFMA16(x[c][t].x, x[s][t].x, a0);
-                a1 = WMF_MFMA16(x[c][t].y, x[s][t].y, a1);
-                a0 = WMF_MFMA16(x[c][t].z, x[s][t].z, a0);
-                a1 = WMF_MFMA16(x[c][t].w, x[s][t].w, a1);
+        for (int t = 0; t < NCH; ++t) {
+            if constexpr (NSETS == 1) {
+                acc[0][0] = WMF_MFMA16(x[0][t].x, x[0][t].x, acc[0][0]);
+                acc1 = WMF_MFMA16(x[0][t].y, x[0][t].y, acc1);
+                acc[0][0] = WMF_MFMA16(x[0][t].z, x[0][t].z, acc[0][0]);
+                acc1 = WMF_MFMA16(x[0][t].w, x[0][t].w, acc1);
+            } else {
+#define WMF_S4(E)                                                                   \
+    _Pragma("unroll") for (int s = 0; s < NSETS; ++s)                               \
+        _Pragma("unroll") for (int c = 0; c < NSETS; ++c) acc[s][c] = WMF_MFMA16(x[c][t].E, x[s][t].E, acc[s][c]);
+                WMF_S4(x) WMF_S4(y) WMF_S4(z) WMF_S4(w)
+#undef WMF_S4
             }
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) Sb[s][c][reg] = a0[reg] + a1[reg];
         }
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s)
+#pragma unroll
+            for (int c = 0; c < NSETS; ++c)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Sb[s][c][reg] = acc[s][c][reg] + (NSETS == 1 ? acc1[reg] : 0.f);
     }
     if constexpr (BLK && NSETS == 2) {
         // ---- symmetric form and 2 x 2 block elimination with 16 x 16 tiles:
@@ -170,16 +184,17 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
                 out[reg] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(caddr[reg], __builtin_bit_cast(int, v)));
         };
         auto qsum = [&](float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };
-        float eA[4], eB[4];
+        float eA[4], eB[4], pA[4], pB[4];
         col4(e0, eA);
         col4(e1, eB);
+        col4(p[0], pA);                                          // 0 for the slots past the row's end, whose S entries are not
+        col4(p[1], pB);
         f32x4 PA, PU, PB, PC;
         float spA = 0.f, spB = 0.f;                              // (S p) of my A row / my B row, partial over my columns
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const float pa = eA[reg] * eA[reg] + 1.f, pb = eB[reg] * eB[reg] + 1.f;
-            spA += Sb[0][0][reg] * pa + Sb[0][1][reg] * pb;
-            spB += Sb[1][0][reg] * pa + Sb[1][1][reg] * pb;
+            spA += Sb[0][0][reg] * pA[reg] + Sb[0][1][reg] * pB[reg];
+            spB += Sb[1][0][reg] * pA[reg] + Sb[1][1][reg] * pB[reg];
             const float dg = (r == 4 * q + reg) ? 1.f : 0.f;
             PA[reg] = dg + e0 * Sb[0][0][reg] * eA[reg];
             PU[reg] = e0 * Sb[0][1][reg] * eB[reg];
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
         if constexpr (NSETS == 2) {
             y.x += p[1] * x[1][t].x; y.y += p[1] * x[1][t].y; y.z += p[1] * x[1][t].z; y.w += p[1] * x[1][t].w;
         }
-        y.x = wmf_row16_sum(y.x); y.y = wmf_row16_sum(y.y); y.z = wmf_row16_sum(y.z); y.w = wmf_row16_sum(y.w);
+        wmf_row16_sum4(y.x, y.y, y.z, y.w);
         const int c = 4 * t + q;
         if (r == 0 && c < nch) grow[c] = y;
     }
