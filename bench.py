@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg2", choices=sorted(synth.CONFIGS))
     ap.add_argument("--zipf", type=float, default=0.0, help="item popularity exponent (0 = uniform)")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="solve each side in this many chunks (0 = engine default: 1 on one GPU, 4 on several, where "
+                         "the all-gather of a chunk overlaps the solve of the next)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-users", type=int, default=0, help="user rows in the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
@@ -76,12 +79,12 @@ def measured_traffic(config, slot, f, ld):
     import glob
     nfb, nch = (f + 15) // 16, (ld + 15) // 16
     key = {0: f"gram_kernel<{nfb}, 1>", 3: f"transform_kernel<{nfb}, true>", 4: f"solve_low_kernel<{nch}, 1>",
-           5: f"solve_low_kernel<{nch}, 2>",
-           11: f"solve_direct64_kernel<{nfb}>" if f <= 64 else f"solve_direct_kernel<{nfb}>"}.get(slot)
+           5: f"solve_low_kernel<{nch}, 2", 11: f"solve_directw_kernel<{nfb}, 0>"}.get(slot)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config}_traffic.json")))
     if not key or not files:
         return None
-    k = json.load(open(files[-1])).get("kernels", {}).get(key)
+    table = json.load(open(files[-1])).get("kernels", {})
+    k = next((v for name, v in table.items() if name.startswith(key)), None)       # template arguments may follow
     if not k or k.get("FETCH_SIZE_KB_mean") is None:
         return None
     return (2.0 * k["FETCH_SIZE_KB_mean"] + k.get("WRITE_SIZE_KB_mean", 0.0)) * 1024.0
@@ -119,7 +122,7 @@ def main():
     counts = torch.cat([p[2] for p in parts])
     del parts, ptrs
     nnz = int(indices.numel())
-    eng = AlsEngine(n_users, n_items, k, bias, gamma, device=dev)
+    eng = AlsEngine(n_users, n_items, k, bias, gamma, device=dev, chunks=args.chunks or None)
     values = counts.clone()
     eng.K.confidence_transform(values, 10.0, 1.0, 0)
     eng.set_interactions(indptr, indices, values)
@@ -214,7 +217,7 @@ def main():
         "config": {"workload": f"{args.config}: WMF k={k}{'+bias' if bias else ''}, {n_users}x{n_items} CSR, "
                                f"{nnz} nnz, alpha-log confidence, gamma={gamma}, zipf_a={args.zipf}",
                    "n_users": n_users, "n_items": n_items, "nnz": nnz, "k": k, "bias": bias,
-                   "sharding": f"users+items round-robin over {world} GPU(s)"},
+                   "sharding": f"users+items round-robin over {world} GPU(s), {len(eng.chunk_bounds['users'])} chunk(s) per side"},
         "nnz_per_s": 2.0 * nnz * args.steps / elapsed,
         "epoch_algorithmic_GBps": epoch_bytes * args.steps / elapsed / 1e9,
         "epoch_hbm_frac": epoch_bytes * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),

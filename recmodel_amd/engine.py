@@ -14,11 +14,18 @@ Restates the control structure of ``WMF.train``'s weighted branch (RecModel/wmf_
 Sharding.  Rows of the side being updated are independent given the
 fixed side, so each rank owns a slice of the users and a slice of the items.  Ids are dealt
 round-robin (id i lives on rank i % W at local index i // W) so that popularity-sorted ids give
-every rank the same number of stored entries; the *position* of id i in a gathered matrix is
-(i % W) * rows_per_rank + i // W.  Per half step the only exchanges are an all-reduce of the
-f x f Gramian (fp64) and an all-gather of the freshly whitened factor block.
+every rank the same number of stored entries.  Per half step the only exchanges are an all-reduce
+of the f x f Gramian (fp64) and the all-gather of the freshly solved factor block, and the gather is
+hidden behind the solve: the local rows are solved in a few CHUNKS, and the all-gather of chunk c runs
+on RCCL's stream while chunk c + 1 is being solved.  What travels is the un-whitened block (its Gramian,
+hence the whitening matrix, only exists once every chunk is done); each rank then whitens the whole
+gathered matrix itself -- a streaming pass at HBM speed, W times redundant, instead of an exposed
+transfer over xGMI.  The gathered matrix is chunk-major so that every all-gather writes one contiguous
+range: with local index j = i // W in chunk c = j // chunk_len (chunk start s_c, length len_c), the
+*position* of id i is  W * s_c + (i % W) * len_c + (j - s_c).  With one rank this is the identity.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -127,10 +134,19 @@ def coo_to_csr(rows, cols, vals, n_rows):
     return indptr, cols[order].to(torch.int32), vals[order]
 
 
+def gathered_positions(ids, world, rows_per_rank, chunk_len):
+    """Row of id ``ids`` in a chunk-major gathered matrix (module docstring).  Works on ints and tensors."""
+    j = ids // world
+    s_c = (j // chunk_len) * chunk_len
+    rest = rows_per_rank - s_c
+    len_c = torch.clamp(rest, max=chunk_len) if torch.is_tensor(rest) else min(chunk_len, rest)
+    return world * s_c + (ids % world) * len_c + (j - s_c)
+
+
 class AlsEngine:
     """Weighted-ALS state of one rank: factor blocks, whitened gathers, CSR shards."""
 
-    def __init__(self, n_users, n_items, dim, bias, gamma, device=None, group=None, kernels=None):
+    def __init__(self, n_users, n_items, dim, bias, gamma, device=None, group=None, kernels=None, chunks=None):
         self.K = kernels if kernels is not None else HipKernels()     # raises without a GPU / built library
         self.lib = getattr(self.K, "lib", None)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -147,12 +163,22 @@ class AlsEngine:
         W = self.world
         self.rpr = {s: (self.n[s] + W - 1) // W for s in self.n}            # rows per rank (padded)
         self.n_local = {s: len(range(self.rank, self.n[s], W)) for s in self.n}
+        if chunks is None:
+            chunks = int(os.environ.get("WMF_CHUNKS", "4")) if W > 1 else 1
+        # chunk c of a side = local rows [c * chunk_len, min((c + 1) * chunk_len, rows_per_rank))
+        self.chunk_len = {s: max(1, (self.rpr[s] + max(1, int(chunks)) - 1) // max(1, int(chunks))) for s in self.n}
+        self.chunk_bounds = {s: [(lo, min(self.chunk_len[s], self.rpr[s] - lo))
+                                 for lo in range(0, max(self.rpr[s], 1), self.chunk_len[s]) if lo < self.rpr[s]]
+                             for s in self.n}
         dev, f32 = self.device, torch.float32
         z = lambda *shape, dtype=f32: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
         # local factor blocks [rows_per_rank, ld]; rows >= n_local are padding and stay zero
         self.factors = {s: z(self.rpr[s], self.ld) for s in self.n}
         self.g = {s: z(self.rpr[s], self.ld) for s in self.n}
-        # gathered whitened factors / bias of the fixed side [W * rows_per_rank, ld]
+        # gathered factors of all ranks (chunk-major positions); with one rank the local block itself
+        self.X = {s: (z(W * self.rpr[s], self.ld) if W > 1 else self.factors[s]) for s in self.n}
+        self._pending = {s: [] for s in self.n}                            # all-gathers in flight
+        # whitened gathered factors / bias of the fixed side [W * rows_per_rank, ld]
         self.V = {s: z(W * self.rpr[s], self.ld) for s in self.n}
         self.bias_vec = {s: z(W * self.rpr[s]) for s in self.n}
         self.G = z(self.f * self.f, dtype=torch.float64)
@@ -163,12 +189,12 @@ class AlsEngine:
         self.eval_ws = torch.empty(self.K.eval_workspace_bytes(), dtype=torch.uint8, device=dev)
         self.eval_out = z(3, dtype=torch.float64)
         self.csr = {}          # "users": shard with local user rows, "items": shard with local item rows
+        self.csr_chunks = {}   # the same rows as one Csr (own row plan) per chunk
         self.has_factors = {"users": False, "items": False}
 
     # ---------------------------------------------------------------- id <-> position maps
     def positions(self, side, ids):
-        W = self.world
-        return (ids % W) * self.rpr[side] + ids // W
+        return gathered_positions(ids, self.world, self.rpr[side], self.chunk_len[side])
 
     def _other(self, side):
         return "items" if side == "users" else "users"
@@ -184,8 +210,18 @@ class AlsEngine:
         vals = values.to(dev, torch.float32)
         counts = indptr[1:] - indptr[:-1]
         rows = torch.repeat_interleave(torch.arange(self.n["users"], device=dev), counts)
-        self.csr["users"] = self._shard("users", rows, cols, vals)
-        self.csr["items"] = self._shard("items", cols, rows, vals)
+        for side, (r_, c_) in (("users", (rows, cols)), ("items", (cols, rows))):
+            full = self._shard(side, r_, c_, vals)
+            self.csr[side] = full
+            bounds = self.chunk_bounds[side]
+            if len(bounds) == 1:
+                self.csr_chunks[side] = [full]
+            else:
+                edges = full.indptr[[lo for lo, _ in bounds] + [self.rpr[side]]].tolist()
+                self.csr_chunks[side] = [
+                    Csr(self.K, full.indptr[lo: lo + ln + 1] - edges[c], full.indices[edges[c]: edges[c + 1]],
+                        full.values[edges[c]: edges[c + 1]], full.n_cols, self.f)
+                    for c, (lo, ln) in enumerate(bounds)]
 
     def _shard(self, side, rows, cols, vals):
         W, r = self.world, self.rank
@@ -205,17 +241,31 @@ class AlsEngine:
         blk.zero_()
         blk[: mine.shape[0], : self.f] = mine
         self.has_factors[side] = True
+        for c in range(len(self.chunk_bounds[side])):
+            self._publish(side, c)
 
     def get_factors(self, side):
-        """Full [n, f] factor matrix on the host (gathers the blocks of all ranks)."""
-        blk = self.factors[side]
-        if self.world > 1:
-            full = torch.empty(self.world * self.rpr[side], self.ld, dtype=torch.float32, device=self.device)
-            torch.distributed.all_gather_into_tensor(full, blk, group=self.group)
-        else:
-            full = blk
+        """Full [n, f] factor matrix on the host, in id order."""
+        self._wait(side)
         ids = torch.arange(self.n[side], device=self.device)
-        return full[self.positions(side, ids)][:, : self.f].cpu().numpy()
+        return self.X[side][self.positions(side, ids)][:, : self.f].cpu().numpy()
+
+    # ---------------------------------------------------------------- exchange
+    def _publish(self, side, c):
+        """Start the all-gather of chunk ``c`` of this rank's freshly written block.  It is ordered after the
+        kernels already enqueued on the current stream and runs beside whatever is enqueued next."""
+        if self.world == 1:
+            return
+        lo, ln = self.chunk_bounds[side][c]
+        W = self.world
+        self._pending[side].append(torch.distributed.all_gather_into_tensor(
+            self.X[side][W * lo: W * (lo + ln)], self.factors[side][lo: lo + ln], group=self.group, async_op=True))
+
+    def _wait(self, side):
+        """Make the current stream wait for every all-gather of ``side`` still in flight."""
+        for work in self._pending[side]:
+            work.wait()
+        self._pending[side] = []
 
     # ---------------------------------------------------------------- one half step
     def prepare(self, fixed):
@@ -228,24 +278,22 @@ class AlsEngine:
             torch.distributed.all_reduce(self.G, group=self.group)
         K.factorize(self.G, self.f, self.ld, self.gamma, self.W_white, self.W_unwhite, self.info, self.ws)
         V, bvec = self.V[fixed], self.bias_vec[fixed]
-        lo = self.rank * self.rpr[fixed]
-        v_loc = V[lo: lo + self.rpr[fixed]]
-        b_loc = bvec[lo: lo + self.rpr[fixed]]
-        K.row_transform(blk, self.n_local[fixed], self.f, self.ld, self.W_white, self.bias, v_loc,
-                        b_loc if self.bias else None)
-        if self.world > 1:
-            torch.distributed.all_gather_into_tensor(V, v_loc, group=self.group)
-            if self.bias:
-                torch.distributed.all_gather_into_tensor(bvec, b_loc, group=self.group)
+        self._wait(fixed)
+        rows = self.n_local[fixed] if self.world == 1 else self.world * self.rpr[fixed]
+        K.row_transform(self.X[fixed], rows, self.f, self.ld, self.W_white, self.bias, V, bvec if self.bias else None)
 
     def update(self, side):
         """Solve every local row of ``side`` against the prepared fixed side.  wmf_model.py:220-239."""
         K = self.K
         fixed = self._other(side)
-        c = self.csr[side]
-        K.solve_rows(c._plan, self.V[fixed], self.bias_vec[fixed] if self.bias else None, c.indptr, c.indices, c.values,
-                     c.n_rows, self.f, self.ld, self.g[side], self.fail)
-        K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, False, self.factors[side], None)
+        bvec = self.bias_vec[fixed] if self.bias else None
+        self._wait(side)                             # nobody may still be reading the block that is about to be rewritten
+        for c, ((lo, ln), csr) in enumerate(zip(self.chunk_bounds[side], self.csr_chunks[side])):
+            g = self.g[side][lo: lo + ln]
+            K.solve_rows(csr._plan, self.V[fixed], bvec, csr.indptr, csr.indices, csr.values, ln, self.f, self.ld, g, self.fail)
+            real = max(0, min(ln, self.n_local[side] - lo))
+            K.row_transform(g, real, self.f, self.ld, self.W_unwhite, False, self.factors[side][lo: lo + ln], None)
+            self._publish(side, c)
         self.has_factors[side] = True
 
     def half_step(self, side):
@@ -263,6 +311,8 @@ class AlsEngine:
         K.spmm_rows(self.V[fixed], c.indptr, c.indices, c.values, c.n_rows, self.f, self.ld, self.g[side])
         K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, False, self.factors[side], None)
         self.has_factors[side] = True
+        for c in range(len(self.chunk_bounds[side])):
+            self._publish(side, c)
 
     def check_numerics(self):
         """Host sync: raise if a Gramian was not positive definite or a row system was singular."""
@@ -285,12 +335,8 @@ class AlsEngine:
     def eval_sums(self, shard):
         """(sum of squared errors, sum of absolute errors, count) over the stored non-zero entries
         of ``shard``; all-reduced over ranks.  base_model.py:163-176."""
-        items = self.factors["items"]
-        if self.world > 1:
-            full = torch.empty(self.world * self.rpr["items"], self.ld, dtype=torch.float32, device=self.device)
-            torch.distributed.all_gather_into_tensor(full, items, group=self.group)
-            items = full
-        self.K.eval_sqerr(self.factors["users"], items, self.f, self.ld, self.bias, shard.indptr, shard.indices,
+        self._wait("items")
+        self.K.eval_sqerr(self.factors["users"], self.X["items"], self.f, self.ld, self.bias, shard.indptr, shard.indices,
                           shard.values, shard.n_rows, self.eval_out, self.eval_ws)
         if self.world > 1:
             torch.distributed.all_reduce(self.eval_out, group=self.group)

@@ -1,8 +1,9 @@
 """world_size-2 gloo test of the multi-rank host path on CPU.
 
-Each rank runs AlsEngine with the NumPy stand-in backend: users and items dealt round-robin, one
-all-reduce of the f x f Gramian and one all-gather of the whitened block per half step, factors
-gathered back in id order.  The result must equal the single-process oracle on the full matrix."""
+Each rank runs AlsEngine with the NumPy stand-in backend: users and items dealt round-robin, local rows
+solved in four chunks whose all-gathers are started asynchronously, one all-reduce of the f x f Gramian per
+half step, the gathered matrix whitened on every rank, factors read back in id order.  The result must
+equal the single-process oracle on the full matrix."""
 import os
 import socket
 import sys
@@ -100,3 +101,10 @@ def test_single_rank_engine_with_stand_in_matches_oracle():
     want = orc.recompute_factors(orc.init_items(n_items, dim), C, 0.1)
     np.testing.assert_allclose(eng.get_factors("users"), want, rtol=2e-4, atol=2e-5)
     assert eng.algorithmic_bytes_half("users") == C.nnz * (4 * 5 + 8) + n_users * (4 * 5 + 4) + 4 * 25 + 4 * n_items * 5
+    # the chunked solve (what multi-rank runs use to overlap the exchange) gives the same rows
+    eng3 = AlsEngine(n_users, n_items, dim, False, 0.1, device="cpu", kernels=NumpyKernels(), chunks=3)
+    eng3.set_interactions(indptr, indices, values)
+    assert len(eng3.csr_chunks["users"]) == 3 and sum(c.nnz for c in eng3.csr_chunks["users"]) == C.nnz
+    eng3.set_factors("items", orc.init_items(n_items, dim))
+    eng3.half_step("users")
+    np.testing.assert_array_equal(eng3.get_factors("users"), eng.get_factors("users"))

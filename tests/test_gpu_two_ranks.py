@@ -1,6 +1,6 @@
 """Two ranks sharing the one GPU of the test box (gloo transport, device tensors): the real HIP
-kernels under the sharded host path -- round-robin ids, padding rows, Gramian all-reduce, all-gather
-of the whitened block -- against the single-process oracle.  (RCCL itself needs one GPU per rank and
+kernels under the sharded host path -- round-robin ids, padding rows, Gramian all-reduce, chunked solve
+with asynchronous all-gathers, whitening of the gathered matrix -- against the single-process oracle.  (RCCL itself needs one GPU per rank and
 is exercised by the driver's multi-GPU bench; NCCL refuses two ranks on one device.)"""
 import os
 import socket

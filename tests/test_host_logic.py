@@ -49,12 +49,25 @@ def test_coo_to_csr_keeps_duplicates_and_order():
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
-def test_round_robin_positions_are_a_bijection(world):
+@pytest.mark.parametrize("chunks", [1, 3, 4])
+def test_gathered_positions_are_a_bijection_and_chunk_contiguous(world, chunks):
+    """Chunk-major layout of the gathered factor matrix (engine module docstring): every id has its own row,
+    and the rows rank r contributes to chunk c are one contiguous range at W * s_c + r * len_c -- what an
+    all_gather_into_tensor of that chunk writes."""
+    import torch
+    from recmodel_amd.engine import gathered_positions
     n = 103
     rpr = (n + world - 1) // world
+    L = max(1, (rpr + chunks - 1) // chunks)
     ids = np.arange(n)
-    pos = (ids % world) * rpr + ids // world
+    pos = gathered_positions(torch.arange(n), world, rpr, L).numpy()
+    assert [gathered_positions(int(i), world, rpr, L) for i in ids] == pos.tolist()      # int and tensor forms agree
     assert len(set(pos.tolist())) == n and pos.max() < world * rpr
     for r in range(world):
-        mine = ids[r::world]
-        np.testing.assert_array_equal(pos[mine], r * rpr + np.arange(len(mine)))   # contiguous block per rank
+        mine = ids[r::world]                                     # local index j <-> id r + W j
+        for s_c in range(0, rpr, L):
+            len_c = min(L, rpr - s_c)
+            j = np.arange(s_c, min(s_c + len_c, len(mine)))
+            np.testing.assert_array_equal(pos[mine[j]], world * s_c + r * len_c + (j - s_c))
+    if world == 1:
+        np.testing.assert_array_equal(pos, ids)
