@@ -107,7 +107,7 @@ def main():
     n_users_1, n_items, dbar, k, bias = synth.CONFIGS[args.config]
     n_users = n_users_1 * world                     # weak scaling over users
     gamma = 0.1
-    seed = 1993 + {"cfg1": 1, "cfg2": 2, "cfg3": 3, "tiny": 9}[args.config]
+    seed = 1993 + {"cfg1": 1, "cfg2": 2, "cfg3": 3, "cfg5s": 5, "tiny": 9}[args.config]
 
     # ---- synthetic workload, generated on the GPU (identical on every rank) -----------------
     t0 = time.perf_counter()
@@ -227,7 +227,7 @@ def main():
         "row_bins": {s: {"rows": eng.csr[s].bin_rows.tolist(), "nnz": eng.csr[s].bin_nnz.tolist()} for s in ("users", "items")},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        su = args.cpu_users or {64: 100_000, 128: 30_000, 16: 943}.get(k, 20_000)
+        su = args.cpu_users or {64: 100_000, 128: 30_000, 16: 943, 256: 8_000}.get(k, 20_000)
         su = min(su, n_users_1)
         si = max(1, min(n_items, su * n_items // n_users_1))
         ip = indptr[: su + 1].cpu().numpy()

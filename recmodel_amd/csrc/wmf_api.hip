@@ -216,6 +216,7 @@ void wmf_plan_destroy(wmf_plan* p) {
     if (p->fallback_rows) (void)hipFree(p->fallback_rows);
     if (p->fallback_count) (void)hipFree(p->fallback_count);
     if (p->w_eff) (void)hipFree(p->w_eff);
+    if (p->wide_ws) (void)hipFree(p->wide_ws);
     if (p->seg_lo) (void)hipFree(p->seg_lo);
     if (p->seg_d) (void)hipFree(p->seg_d);
     if (p->seg_first) (void)hipFree(p->seg_first);
@@ -238,8 +239,8 @@ int wmf_solve_rows(const wmf_plan* plan, const float* V, const float* bias_fixed
     if (plan->n != n || plan->f != f) { wmf_set_error("wmf_solve_rows: plan was built for n=%lld f=%d", (long long)plan->n, plan->f); return WMF_EINVAL; }
     if (n == 0) return WMF_OK;
     const int lrc = wmf_launch_solve(plan, V, bias_fixed, indptr, indices, values, f, ld, g, fail_count, (hipStream_t)stream);
-    if (lrc == -2) { wmf_set_error("wmf_solve_rows: hipMemsetAsync failed"); return WMF_EHIP; }
-    if (lrc) { wmf_set_error("wmf_solve_rows: rows with more than 32 stored entries need f <= 144 in this build (f=%d)", f); return WMF_EINVAL; }
+    if (lrc == -2) { wmf_set_error("wmf_solve_rows: device allocation or memset failed"); return WMF_EHIP; }
+    if (lrc) { wmf_set_error("wmf_solve_rows: no kernel for f=%d, ld=%d", f, ld); return WMF_EINVAL; }
     return check_launch("wmf_solve_rows");
 }
 

@@ -7,6 +7,7 @@
 #define WMF_EVAL_MAX_BLOCKS 2048
 #define WMF_HEAVY_T 4096      /* rows with more stored entries are accumulated by several waves ... */
 #define WMF_SEG 2048          /* ... in segments of this many entries */
+#define WMF_WIDE_LU_GRID 64   /* workgroups (and workspace slices) of the pivoted-LU fallback for f > 144 */
 
 // row-degree bins of a plan
 enum { WMF_BIN_LOW16 = 0, WMF_BIN_LOW32 = 1, WMF_BIN_MFMA = 2, WMF_BIN_GENERAL = 3, WMF_NBINS = 4 };
@@ -27,6 +28,7 @@ struct wmf_plan {
     int32_t* seg_d;            // device: entries in each segment
     int32_t* seg_first;        // device: heavy_count + 1 prefix of segment counts
     float* partial;            // device: seg_total x (tiles x 256) partial accumulators
+    float* wide_ws;            // device: workspace of the f > 144 pivoted-LU fallback, allocated on first use
 };
 
 int wmf_gram_max_waves(int f);
@@ -50,6 +52,14 @@ int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* biasv, c
 int wmf_launch_direct64(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                         const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
                         int32_t* fb_count, hipStream_t st);
+int wmf_wide_supported(int f);
+int wmf_launch_wide(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
+                    const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
+                    int32_t* fb_count, hipStream_t st);
+size_t wmf_wide_lu_workspace_bytes(int f);
+int wmf_launch_wide_lu(const int32_t* rows, const int32_t* count_ptr, const float* V, const float* biasv,
+                       const int64_t* indptr, const int32_t* indices, const float* vals, int f, int ld, float* g,
+                       int32_t* fail_count, float* work, hipStream_t st);
 int wmf_launch_spmm(const float* V, const int64_t* indptr, const int32_t* indices, const float* values, int64_t n,
                     int ld, float* g, hipStream_t st);
 int wmf_launch_eval(const float* users, const float* items, int f, int ld, int bias, const int64_t* indptr,

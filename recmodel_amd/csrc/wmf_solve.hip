@@ -527,18 +527,24 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
         if (rc) return -1;
     }
     if (pl->count[WMF_BIN_GENERAL] > 0) {
-        if (!general_ok) return -1;
-        const int64_t heavy = pl->count[WMF_BIN_GENERAL];
-        int grid = (int)(heavy < 4096 ? heavy : 4096);
+        // f > 144: rows with more than 32 entries go to the workgroup-per-row kernel (wmf_wide.hip)
+        if (!wmf_wide_supported(f)) return -1;
         WmfProfScope ps(WMF_SLOT_SOLVE_HEAVY, st);
-        if (dispatch_general(pl->rows[WMF_BIN_GENERAL], heavy, nullptr, grid, V, biasv, indptr, indices, vals, f, ld, g,
-                             fail_count, st)) return -1;
+        if (wmf_launch_wide(pl->rows[WMF_BIN_GENERAL], pl->count[WMF_BIN_GENERAL], V, biasv, indptr, indices, vals, f, ld, g,
+                            pl->fallback_rows, pl->fallback_count, st)) return -1;
     }
-    if (general_ok) {
+    {
         // rows bounced by the other kernels (negative weights / not positive definite); count is on the device
         WmfProfScope ps(WMF_SLOT_SOLVE_FALLBACK, st);
-        if (dispatch_general(pl->fallback_rows, 0, pl->fallback_count, 256, V, biasv, indptr, indices, vals, f, ld, g,
-                             fail_count, st)) return -1;
+        if (general_ok) {
+            if (dispatch_general(pl->fallback_rows, 0, pl->fallback_count, 256, V, biasv, indptr, indices, vals, f, ld, g,
+                                 fail_count, st)) return -1;
+        } else {
+            wmf_plan* plm = const_cast<wmf_plan*>(pl);
+            if (!plm->wide_ws && hipMalloc((void**)&plm->wide_ws, wmf_wide_lu_workspace_bytes(f)) != hipSuccess) return -2;
+            if (wmf_launch_wide_lu(pl->fallback_rows, pl->fallback_count, V, biasv, indptr, indices, vals, f, ld, g, fail_count,
+                                   plm->wide_ws, st)) return -1;
+        }
     }
     return 0;
 }

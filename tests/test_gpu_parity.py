@@ -21,6 +21,7 @@ from oracle import wmf_oracle as orc
 pytestmark = pytest.mark.gpu
 
 HALF_FRO, HALF_ROW = 5e-5, 5e-4
+WIDE_FRO, WIDE_ROW = 1.5e-4, 1e-3          # f > 144 (k = 256): conditioning grows with f; DESIGN.md section 2 numerics
 TRAIN_FRO, TRAIN_MSE = 1e-3, 1e-4
 
 
@@ -145,9 +146,10 @@ def ragged_matrix(n, m, seed, dtype=np.float32):
     return D
 
 
-@pytest.mark.parametrize("k,bias", [(16, False), (64, False), (64, True), (128, False), (128, True), (50, False), (33, True)])
+@pytest.mark.parametrize("k,bias", [(16, False), (64, False), (64, True), (128, False), (128, True), (50, False), (33, True),
+                                    (256, False), (256, True), (150, False), (200, True)])
 def test_half_step_vs_oracle_all_degree_classes(WMF, k, bias):
-    n, m_items = 2500, 600
+    n, m_items = (2500, 600) if k <= 128 else (900, 500)     # the NumPy oracle is O(f^3) per row
     C = ragged_matrix(n, m_items, seed=k + bias)
     model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=bias)
     # one oracle iteration first so the factors are "trained-like" rather than uniform noise
@@ -158,15 +160,18 @@ def test_half_step_vs_oracle_all_degree_classes(WMF, k, bias):
         want = step_o(Y, as_f64(mat), 0.1, out_dtype="float64")
         got = step_g(Y, mat, 0.1)
         rel, zero_abs = worst_row(got, want)
-        assert fro(got, want) <= HALF_FRO, (k, bias, fro(got, want))
-        assert rel <= HALF_ROW and zero_abs == 0.0, (k, bias, rel, zero_abs)
+        tol_fro, tol_row = (HALF_FRO, HALF_ROW) if k + bias <= 144 else (WIDE_FRO, WIDE_ROW)
+        assert fro(got, want) <= tol_fro, (k, bias, fro(got, want))
+        assert rel <= tol_row and zero_abs == 0.0, (k, bias, rel, zero_abs)
         assert not np.isnan(got).any()
 
 
-def test_negative_weights_take_the_pivoted_path(WMF):
+@pytest.mark.parametrize("k", [16, 256])
+def test_negative_weights_take_the_pivoted_path(WMF, k):
     """bias model with large fixed-side biases: w - bias < 0 for many entries, so A_u is not SPD
-     and the rows must go through the LU kernel."""
-    n, m_items, k = 400, 150, 16
+     and the rows must go through the LU kernel (LDS version for f <= 144, the
+    global-workspace version above that)."""
+    n, m_items = 400, 150
     C = ragged_matrix(n, m_items, seed=77)
     model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=True)
     Y = model.items.copy()
