@@ -94,24 +94,30 @@ __device__ __forceinline__ float wmf_bcast_rowgroup(float v) {
 // In-place Gauss-Jordan inverse of a symmetric positive definite 16 x 16 tile held row-distributed:
 // lane (r, q) has A[r][4q + reg] in a[reg].  Step K: column K becomes e_K first, then every row gets
 // row_i += nf_i * row_K with nf = -A[i][K]/piv (rows i != K) or 1/piv - 1 (row K).
-template <int K>
+// The multiplier A[r][K] sits in lane (r, K / 4); LDS = true fetches it with one ds_bpermute (one LDS instruction,
+// long latency), false with two VALU lane swaps (five VALU instructions, no LDS round trip).
+// CHECK = false skips the pivot test: for callers whose tile is positive definite by construction (pivots >= 1)
+// and who test the result for NaN / Inf anyway.
+template <int K, bool LDS, bool CHECK>
 __device__ __forceinline__ void gj_inv_step(f32x4& a, const int (&baddr)[4], int r, int q, bool& ok) {
     constexpr int kq = K >> 2, kr = K & 3;
     const float akr = a[kr];     // copy first: __builtin_bit_cast applied to the vector-element lvalue itself reads element 0
     const float piv = rlw(akr, K + 16 * kq);
-    if (!(piv > 1e-20f)) ok = false;
+    if constexpr (CHECK) { if (!(piv > 1e-20f)) ok = false; }
     const float inv = __builtin_amdgcn_rcpf(piv);
-    const float fk = wmf_bcast_rowgroup<kq>(akr);     // A[r][K] sits in lane (r, kq): VALU swaps instead of a ds_bpermute round trip
+    float fk;
+    if constexpr (LDS) fk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(baddr[kq], __builtin_bit_cast(int, akr)));
+    else               fk = wmf_bcast_rowgroup<kq>(akr);
     if (q == kq) a[kr] = (r == K) ? 1.f : 0.f;
     const float nf = (r == K) ? inv - 1.f : -fk * inv;
     float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
     fmac_bcast4_self<K>(a0, a1, a2, a3, nf);
     a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3;
 }
-template <int... Ks>
+template <bool LDS = true, bool CHECK = true, int... Ks>
 __device__ __forceinline__ void gj_inv_sweep(f32x4& a, const int (&baddr)[4], int r, int q, bool& ok,
                                              std::integer_sequence<int, Ks...>) {
-    (gj_inv_step<Ks>(a, baddr, r, q, ok), ...);
+    (gj_inv_step<Ks, LDS, CHECK>(a, baddr, r, q, ok), ...);
 }
 
 static inline int wmf_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

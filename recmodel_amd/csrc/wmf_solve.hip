@@ -80,8 +80,13 @@ __device__ __forceinline__ void gj_sweep(float (&m)[NSETS][NSETS * 4], float (&p
 // r == j (set A) or r == j - 16 (set B, NSETS == 2).  Each lane loads 16-byte pieces
 // V[idx][16 t + 4 q .. +3]; element e of piece t is the MFMA operand of step (t, e) for k slot q.
 // Because S = V_u V_u^T, the same register is the A and the B operand.
+#ifndef WMF_LOW_ABLATE
+#define WMF_LOW_ABLATE 0
+#endif
+// d <= 16 rows are latency bound: six waves per SIMD (<= 80 registers, no spills up to NCH = 9) measured 15 % faster
+// than the five the compiler settles on at k = 128; the d <= 32 kernel needs its 100 registers.
 template <int NCH, int NSETS, bool BLK>
-__global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restrict__ rows, int64_t count,
+__global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : 1) void solve_low_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                         const float* __restrict__ V, const float* __restrict__ biasv,
                                                         const int64_t* __restrict__ indptr,
                                                         const int32_t* __restrict__ indices,
@@ -141,6 +146,14 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
     // ---- S blocks by MFMA: Sb[s][c][reg] = S[row r + 16 s][col 16 c + 4 q + reg].  acc layout is D[4q + reg][r];
     //      S symmetric, so tile(a = x[c], b = x[s]) = S[set c row 4q+reg][set s row r] = S[set s row r][set c row 4q+reg].
     float Sb[NSETS][NSETS][4];
+#if WMF_LOW_ABLATE & 1                                 // timing experiments only (tools/kernel_lab.py): no S tiles
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s)
+#pragma unroll
+        for (int c = 0; c < NSETS; ++c)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Sb[s][c][reg] = 1e-3f * (x[s][reg % NCH].x + x[c][(reg + 1) % NCH].y + x[s][NCH - 1].z);
+#else
     {
         // one accumulator per tile; the NSETS^2 tiles are interleaved so that dependent MFMAs are NSETS^2 - 1
         // (NSETS = 1: 0, hence two chains there) instructions apart
@@ -169,14 +182,26 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
 #pragma unroll
             for (int c = 0; c < NSETS; ++c)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Sb[s][c][reg] = acc[s][c][reg] + (NSETS == 1 ? acc1[reg] : 0.f);
+                for (int reg = 0; reg < 4; ++reg) {
+                    if constexpr (NSETS == 1) Sb[s][c][reg] = acc[s][c][reg] + acc1[reg];
+                    else Sb[s][c][reg] = acc[s][c][reg];
+                }
     }
+#endif
+#if WMF_LOW_ABLATE & 2                                 // no solve: c = p + (something that keeps S alive)
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s)
+#pragma unroll
+        for (int c = 0; c < NSETS; ++c) p[s] += w[s] * (Sb[s][c][0] + Sb[s][c][1] + Sb[s][c][2] + Sb[s][c][3]);
+    if constexpr (false) {
+#else
     if constexpr (BLK && NSETS == 2) {
+#endif
         // ---- symmetric form and 2 x 2 block elimination with 16 x 16 tiles:
         //   c = p - E y,   (I + E S E) y = E S p,   E = diag(sqrt(w))        (equal to (I + D S)^-1 p)
         //   P = [[A, U], [B, C]],  B = U^T:  X = A^-1 (tile Gauss-Jordan), T = B X and S' = C - T B^T by MFMA on the
         //   row-distributed registers (MFMA(RD(X), RD(Y)) = RD(Y X^T)), then two tile solves for the vectors.
-        const float e0 = sqrtf(w[0]), e1 = sqrtf(w[1]);
+        const float e0 = __builtin_amdgcn_sqrtf(w[0]), e1 = __builtin_amdgcn_sqrtf(w[1]);   // raw v_sqrt_f32 (1 ulp): E only has to satisfy E^2 ~ D
         const int caddr[4] = {(4 * q + 0) * 4, (4 * q + 1) * 4, (4 * q + 2) * 4, (4 * q + 3) * 4};   // lane of entry 4q + reg (q = 0 row)
         auto col4 = [&](float v, float (&out)[4]) {             // out[reg] = value of row 4q + reg
 #pragma unroll
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
         float tB = e1 * qsum(spB);
         bool okb = true;
         f32x4 X = PA;
-        gj_inv_sweep(X, baddr, r, q, okb, std::make_integer_sequence<int, 16>{});
+        gj_inv_sweep<true, false>(X, baddr, r, q, okb, std::make_integer_sequence<int, 16>{});   // w >= 0: I + E S_AA E is SPD, pivots >= 1
         f32x4 T = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) T = WMF_MFMA16(X[e], PB[e], T);               // RD(B X)
@@ -237,7 +262,9 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg)
                     m[s][c * 4 + reg] = w[s] * Sb[s][c][reg] + ((s == c && r == 4 * q + reg) ? 1.f : 0.f);
+#if !(WMF_LOW_ABLATE & 2)
         gj_sweep<NSETS>(m, p, d, baddr, r, std::make_integer_sequence<int, 4 * NSETS>{});
+#endif
     }
     // With w >= 0 every pivot is >= 1 in exact arithmetic, so the sweep cannot break down; a NaN/Inf
     // in the inputs is what is left to catch, and it survives into c.
@@ -257,7 +284,9 @@ __global__ __launch_bounds__(256) void solve_low_kernel(const int32_t* __restric
         if constexpr (NSETS == 2) {
             y.x += p[1] * x[1][t].x; y.y += p[1] * x[1][t].y; y.z += p[1] * x[1][t].z; y.w += p[1] * x[1][t].w;
         }
+#if !(WMF_LOW_ABLATE & 4)
         wmf_row16_sum4(y.x, y.y, y.z, y.w);
+#endif
         const int c = 4 * t + q;
         if (r == 0 && c < nch) grow[c] = y;
     }
