@@ -121,6 +121,28 @@ int wmf_predict_pairs(const float* users, const float* items, int f, int ld, int
                       const int32_t* users_idx, int64_t n_u, const int32_t* items_idx, int64_t n_i,
                       float* out, void* stream);
 
+/* WMF.rank, wmf_model.py:25-47: scores of ONE user (*user_idx, device) against n_cand candidate item rows
+ * (cand_idx, device), sorted by score, best first.  out_pos[k] = position in cand_idx of the k-th best
+ * candidate (the reference returns items[order]); ties keep candidate order (the reference's tie order is
+ * whatever argpartition / argsort leave).  out_scores may be NULL.  1 <= topn <= n_cand.
+ * workspace: wmf_rank_workspace_bytes(n_cand) bytes of device memory. */
+int64_t wmf_rank_workspace_bytes(int64_t n_cand);
+int wmf_rank_topn(const float* users, const float* items, int f, int ld, int bias, const int32_t* user_idx,
+                  const int32_t* cand_idx, int64_t n_cand, int64_t topn, int32_t* out_pos, float* out_scores,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+/* RecModel.eval_topn / compute_hit, base_model.py:51-148, for all test entries at once.
+ * Test entry p = (pair_user[p], pair_item[p]); its user's random candidates are row pair_row[p] of
+ * candidates[n_rows][n_cand] (item rows, drawn by the caller exactly as base_model.py:62-63 draws them) and
+ * position slot[pair_row[p]] of that row is where the reference writes the test item (:84).
+ * hits[t] = number of test entries whose item is among the topn[t] best of its candidate row, i.e. for
+ * which fewer than topn[t] of the other n_cand - 1 candidates score strictly higher (:86-93).
+ * All arrays on the device; hits is int64[n_topn], n_topn <= 64. */
+int wmf_hit_counts(const float* users, const float* items, int f, int ld, int bias,
+                   const int32_t* pair_user, const int32_t* pair_item, const int32_t* pair_row, int64_t n_pairs,
+                   const int32_t* candidates, int32_t n_cand, const int32_t* slot,
+                   const int32_t* topn, int32_t n_topn, int64_t* hits, void* stream);
+
 /* g[u, :] = sum_j values[j] * V[indices[j], :]  (CSR x dense), the SpMM of the un-weighted
  * closed form wmf_model.py:85,88 in whitened coordinates. */
 int wmf_spmm_rows(const float* V, const int64_t* indptr, const int32_t* indices, const float* values,

@@ -148,6 +148,34 @@ def rank(users_f, items_f, items, user, topn=None, bias=False):
     return items[np.argsort(scores)[-topn:]][::-1]
 
 
+def eval_topn(users_f, items_f, test_mat, topn, rand_sampled=1000, random_state=None, bias=False, return_hits=False):
+    """Recall@N of each test entry among ``rand_sampled`` random candidates.
+    RecModel/base_model.py:100-148 (eval_topn, cores == 1) with compute_hit :51-98 inlined; the legacy
+    np.random stream is consumed in the same order: per user WITH test entries one randint draw of
+    rand_sampled + 1 candidates, then one randint draw of the slot the test item is written to."""
+    if random_state is not None:
+        np.random.seed(random_state)
+    if not isinstance(topn, np.ndarray):
+        raise ValueError("Topn has to be a np.array")
+    num_items = items_f.shape[0]
+    hits = np.zeros(topn.shape, dtype="float32")
+    for user in range(test_mat.shape[0]):
+        test_idx = test_mat.indices[test_mat.indptr[user]:test_mat.indptr[user + 1]]
+        if len(test_idx) == 0:
+            continue
+        cand = np.random.randint(0, num_items, size=(rand_sampled + 1))
+        slot = np.random.randint(0, rand_sampled - (2 * topn.max()))
+        for item in test_idx:
+            cand[slot] = item
+            best = rank(users_f, items_f, cand, user, topn=topn.max(), bias=bias)
+            for pos in range(len(topn)):
+                if item in best[:topn[pos]]:
+                    hits[pos] += 1
+    recall = hits / len(test_mat.nonzero()[0])
+    out = {f"Recall@{topn[pos]}": recall[pos] for pos in range(len(topn))}
+    return (out, hits) if return_hits else out
+
+
 # ------------------------------------------------------------- un-weighted branch
 def unweighted_half_steps(items_f, utility_mat, gamma, dim, dtype="float32"):
     """One iteration of the closed-form un-weighted branch.  RecModel/wmf_model.py:85,88."""

@@ -75,9 +75,20 @@ class RecModel:
                     hits[pos] += 1
         return hits
 
+    def _hit_counts(self, pair_user, pair_item, pair_row, candidates, slot, topn):
+        """Hook for a device implementation of compute_hit over all test entries at once: entry p is
+        (pair_user[p], pair_item[p]) with candidate row ``candidates[pair_row[p]]`` whose position
+        ``slot[pair_row[p]]`` holds the test item.  Returns hits per topn, or None when not provided."""
+        return None
+
     def eval_topn(self, test_mat, train_mat=None, eval_mat=None, topn=[10], rand_sampled=1000, cores=1,
                   random_state=None, dtype='float32'):
-        """Recall@N with sampled negatives.  base_model.py:100-148."""
+        """Recall@N with sampled negatives.  base_model.py:100-148.
+
+        The random candidates are drawn on the host exactly as compute_hit draws them (users in row order,
+        only users with test entries; candidates first, then the slot), so a seeded call samples what the
+        reference samples.  Models that provide ``_hit_counts`` then rank every test entry in one device
+        launch (``cores`` has no meaning there); others go through ``rank`` entry by entry like the reference."""
         super_mat = test_mat
         if train_mat is not None:
             super_mat += train_mat
@@ -87,13 +98,26 @@ class RecModel:
             np.random.seed(random_state)
         if not isinstance(topn, np.ndarray):
             raise ValueError("Topn has to be a np.array")
-        hits = np.zeros(topn.shape, dtype=dtype)
-        if cores == 1:
-            for elem in iter_rows_two_matrices(super_mat, test_mat):
-                hits += self.compute_hit(elem, rand_sampled=rand_sampled, topn=topn)
+        n_test = len(test_mat.nonzero()[0])
+        if type(self)._hit_counts is RecModel._hit_counts:
+            hits = np.zeros(topn.shape, dtype=dtype)
+            if cores == 1:
+                for elem in iter_rows_two_matrices(super_mat, test_mat):
+                    hits += self.compute_hit(elem, rand_sampled=rand_sampled, topn=topn)
+            else:
+                with Pool(cores) as pool:
+                    fn = partial(self.compute_hit, rand_sampled=rand_sampled, topn=topn)
+                    hits = np.stack(pool.map(fn, iter_rows_two_matrices(super_mat, test_mat))).sum(axis=0)
         else:
-            with Pool(cores) as pool:
-                fn = partial(self.compute_hit, rand_sampled=rand_sampled, topn=topn)
-                hits = np.stack(pool.map(fn, iter_rows_two_matrices(super_mat, test_mat))).sum(axis=0)
-        recall = hits / len(test_mat.nonzero()[0])
+            per_row = np.diff(test_mat.indptr)
+            rows = np.flatnonzero(per_row)
+            cand = np.empty((len(rows), rand_sampled + 1), dtype=np.int32)
+            slot = np.empty(len(rows), dtype=np.int32)
+            for k in range(len(rows)):                            # the draws of compute_hit, in its order
+                cand[k] = np.random.randint(0, self.num_items, size=(rand_sampled + 1))
+                slot[k] = np.random.randint(0, rand_sampled - (2 * topn.max()))
+            pair_user = np.repeat(np.arange(test_mat.shape[0]), per_row)
+            pair_row = np.repeat(np.arange(len(rows)), per_row[rows])
+            hits = np.asarray(self._hit_counts(pair_user, test_mat.indices, pair_row, cand, slot, topn)).astype(dtype)
+        recall = hits / n_test
         return {f"Recall@{topn[pos]}": recall[pos] for pos in range(len(topn))}

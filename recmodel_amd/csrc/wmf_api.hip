@@ -268,6 +268,40 @@ int wmf_predict_pairs(const float* users, const float* items, int f, int ld, int
     return check_launch("wmf_predict_pairs");
 }
 
+int64_t wmf_rank_workspace_bytes(int64_t n_cand) { return wmf_rank_ws_bytes(n_cand); }
+
+int wmf_rank_topn(const float* users, const float* items, int f, int ld, int bias, const int32_t* user_idx,
+                  const int32_t* cand_idx, int64_t n_cand, int64_t topn, int32_t* out_pos, float* out_scores,
+                  void* workspace, int64_t workspace_bytes, void* stream) {
+    int rc = check_shape(f, ld);
+    if (rc) return rc;
+    if (!users || !items || !user_idx || !cand_idx || !out_pos || !workspace) { wmf_set_error("wmf_rank_topn: null pointer"); return WMF_EINVAL; }
+    if (n_cand < 1 || n_cand > 0x7fffffffLL || topn < 1 || topn > n_cand) {
+        wmf_set_error("wmf_rank_topn: need 1 <= topn <= n_cand < 2^31 (topn=%lld, n_cand=%lld)", (long long)topn, (long long)n_cand);
+        return WMF_EINVAL;
+    }
+    const int lrc = wmf_launch_rank(users, items, f, ld, bias, user_idx, cand_idx, n_cand, topn, out_pos, out_scores, workspace,
+                                    workspace_bytes, (hipStream_t)stream);
+    if (lrc == -3) { wmf_set_error("wmf_rank_topn: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)wmf_rank_ws_bytes(n_cand)); return WMF_EINVAL; }
+    if (lrc) { wmf_set_error("wmf_rank_topn: device sort or copy failed"); return WMF_EHIP; }
+    return check_launch("wmf_rank_topn");
+}
+
+int wmf_hit_counts(const float* users, const float* items, int f, int ld, int bias, const int32_t* pair_user,
+                   const int32_t* pair_item, const int32_t* pair_row, int64_t n_pairs, const int32_t* candidates,
+                   int32_t n_cand, const int32_t* slot, const int32_t* topn, int32_t n_topn, int64_t* hits, void* stream) {
+    int rc = check_shape(f, ld);
+    if (rc) return rc;
+    if (!users || !items || !topn || !hits || n_pairs < 0 || n_topn < 1 || n_topn > 64 || n_cand < 1) {
+        wmf_set_error("wmf_hit_counts: bad arguments (n_pairs=%lld, n_cand=%d, n_topn=%d)", (long long)n_pairs, n_cand, n_topn);
+        return WMF_EINVAL;
+    }
+    if (n_pairs > 0 && (!pair_user || !pair_item || !pair_row || !candidates || !slot)) { wmf_set_error("wmf_hit_counts: null pointer"); return WMF_EINVAL; }
+    if (wmf_launch_hits(users, items, ld, bias, pair_user, pair_item, pair_row, n_pairs, candidates, n_cand, slot, topn, n_topn,
+                        hits, (hipStream_t)stream)) { wmf_set_error("wmf_hit_counts: hipMemsetAsync failed"); return WMF_EHIP; }
+    return check_launch("wmf_hit_counts");
+}
+
 int wmf_spmm_rows(const float* V, const int64_t* indptr, const int32_t* indices, const float* values, int64_t n, int f,
                   int ld, float* g, void* stream) {
     int rc = check_shape(f, ld);

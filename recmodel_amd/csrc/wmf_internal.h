@@ -67,6 +67,13 @@ int wmf_launch_eval(const float* users, const float* items, int f, int ld, int b
                     hipStream_t st);
 int wmf_launch_predict(const float* users, const float* items, int f, int ld, int bias, const int32_t* ui, int64_t n_u,
                        const int32_t* ii, int64_t n_i, float* out, hipStream_t st);
+int wmf_launch_hits(const float* users, const float* items, int ld, int bias, const int32_t* pair_user,
+                    const int32_t* pair_item, const int32_t* pair_row, int64_t n_pairs, const int32_t* cand, int n_cand,
+                    const int32_t* slot, const int32_t* topn, int n_topn, int64_t* hits, hipStream_t st);
+int64_t wmf_rank_ws_bytes(int64_t n);
+int wmf_launch_rank(const float* users, const float* items, int f, int ld, int bias, const int32_t* user_idx,
+                    const int32_t* cand, int64_t n, int64_t topn, int32_t* out_pos, float* out_scores, void* ws,
+                    int64_t ws_bytes, hipStream_t st);
 int wmf_launch_confidence(float* values, int64_t nnz, double alpha, double beta, int mode, hipStream_t st);
 
 void wmf_set_error(const char* fmt, ...);

@@ -170,12 +170,20 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : 1) void solve_l
                 acc[0][0] = WMF_MFMA16(x[0][t].z, x[0][t].z, acc[0][0]);
                 acc1 = WMF_MFMA16(x[0][t].w, x[0][t].w, acc1);
             } else {
+                // S_BA = S_AB^T is not accumulated: it is one tile transpose (4 MFMAs against the identity) below
 #define WMF_S4(E)                                                                   \
     _Pragma("unroll") for (int s = 0; s < NSETS; ++s)                               \
-        _Pragma("unroll") for (int c = 0; c < NSETS; ++c) acc[s][c] = WMF_MFMA16(x[c][t].E, x[s][t].E, acc[s][c]);
+        _Pragma("unroll") for (int c = s; c < NSETS; ++c) acc[s][c] = WMF_MFMA16(x[c][t].E, x[s][t].E, acc[s][c]);
                 WMF_S4(x) WMF_S4(y) WMF_S4(z) WMF_S4(w)
 #undef WMF_S4
             }
+        }
+        if constexpr (NSETS == 2) {
+            // MFMA(RD(X), RD(Y)) = RD(Y X^T) for row-distributed tiles: with Y = I this is the transpose, exactly
+            f32x4 tr = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tr = WMF_MFMA16(acc[0][1][e], (r == 4 * q + e) ? 1.f : 0.f, tr);
+            acc[1][0] = tr;
         }
 #pragma unroll
         for (int s = 0; s < NSETS; ++s)

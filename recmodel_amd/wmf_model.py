@@ -92,17 +92,45 @@ class WMF(RecModel):
 
     # ------------------------------------------------------------------ a10: rank
     def rank(self, items, users, topn=None):
-        """Top-n of the candidate ``items`` for a user, best first.  wmf_model.py:25-47."""
+        """Top-n of the candidate ``items`` for a user, best first.  wmf_model.py:25-47.
+        Scores and ordering both happen on the device (wmf_rank_topn); equal scores keep candidate order."""
         if topn is None:
             topn = len(items)
         if isinstance(users, list):
             return [self.rank(items, user, topn) for user in users]
         if not type(items) == np.ndarray:
             items = np.array(items)
-        scores = self.predict(users=users, items=items)
-        if len(scores) * 0.5 > topn:
-            return items[np.argpartition(scores, list(range(-topn, 0, 1)))[-topn:]][::-1]
-        return items[np.argsort(scores)[-topn:]][::-1]
+        n = len(items)
+        keep = min(int(topn), n)
+        if keep <= 0:
+            return items[:0]
+        u = int(np.asarray(users).reshape(-1)[0])
+        idx = np.asarray(items).astype(np.int64)
+        if not (-self.users.shape[0] <= u < self.users.shape[0]) or idx.min() < -self.items.shape[0] or idx.max() >= self.items.shape[0]:
+            raise IndexError("user or item index out of bounds")
+        idx = np.where(idx < 0, idx + self.items.shape[0], idx).astype(np.int32)
+        users_t, items_t, f, ld = self._device_factors()
+        lib = _lib.load()
+        ut = torch.tensor([u % self.users.shape[0]], dtype=torch.int32, device="cuda")
+        it = torch.from_numpy(idx).cuda()
+        ws_bytes = int(lib.wmf_rank_workspace_bytes(n))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+        pos = torch.empty(keep, dtype=torch.int32, device="cuda")
+        _lib.check(lib.wmf_rank_topn(_ptr(users_t), _ptr(items_t), f, ld, int(self.bias is True), _ptr(ut), _ptr(it), n, keep,
+                                     _ptr(pos), None, _ptr(ws), ws_bytes, _stream()))
+        return items[pos.cpu().numpy()]
+
+    def _hit_counts(self, pair_user, pair_item, pair_row, candidates, slot, topn):
+        """compute_hit (base_model.py:51-98) for every test entry in one launch: wmf_hit_counts."""
+        users_t, items_t, f, ld = self._device_factors()
+        lib = _lib.load()
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).cuda()   # noqa: E731
+        pu, pi, pr, cd, sl, tn = dev(pair_user), dev(pair_item), dev(pair_row), dev(candidates), dev(slot), dev(topn)
+        hits = torch.zeros(len(topn), dtype=torch.int64, device="cuda")
+        _lib.check(lib.wmf_hit_counts(_ptr(users_t), _ptr(items_t), f, ld, int(self.bias is True), _ptr(pu), _ptr(pi), _ptr(pr),
+                                      len(pair_user), _ptr(cd), candidates.shape[1], _ptr(sl), _ptr(tn), len(topn), _ptr(hits),
+                                      _stream()))
+        return hits.cpu().numpy()
 
     # ------------------------------------------------------------------ a8: eval_prec backend
     def _eval_sums(self, utility_mat):

@@ -174,6 +174,24 @@ def main():
     out.update(csr_fields("util", util))
     np.savez_compressed(f"{OUT}/train_unweighted.npz", **out)
 
+    # ---- sampled Recall@N (eval_topn -> compute_hit -> rank), seeded ---------------
+    for bias in (False, True):
+        counts = make_counts(80, 120, 6, seed=41 + bias, dtype="float64")
+        mdl = WMF(num_items=120, num_users=80, dim=8, gamma=0.1, weighted=True, bias=bias, seed=1993)
+        mdl.train(utility_mat=counts.copy(), count_mat=counts.copy(), iterations=2, eval_mat=counts.copy(), cores=1,
+                  stopping_rounds=5)
+        rng = np.random.Generator(np.random.PCG64(5 + bias))
+        coo = counts.tocoo()
+        keep = rng.random(coo.nnz) < 0.15                       # a sparse test split; several users end up without test items
+        keep &= coo.row % 7 != 3
+        test = sp.csr_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=counts.shape)
+        topn = np.array([1, 5, 10])
+        res = mdl.eval_topn(test_mat=test.copy(), topn=topn, rand_sampled=40, random_state=11)
+        out = dict(users=mdl.users, items=mdl.items, topn=topn, rand_sampled=40, random_state=11,
+                   recall=np.array([res[f"Recall@{n}"] for n in topn], dtype=np.float64), n_test=len(test.nonzero()[0]))
+        out.update(csr_fields("test", test))
+        np.savez_compressed(f"{OUT}/eval_topn_bias{int(bias)}.npz", **out)
+
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(f"{OUT}/{f}"))

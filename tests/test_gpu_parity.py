@@ -107,6 +107,51 @@ def test_predict_rank_on_reference_factors(WMF):
         np.testing.assert_allclose(m.eval_prec(util), float(g["mse_final"]), rtol=1e-5)
 
 
+@pytest.mark.parametrize("bias", [False, True])
+def test_eval_topn_matches_reference_golden(WMF, bias):
+    """Sampled Recall@N on the device (wmf_hit_counts: every test entry ranked among its user's random
+    candidates in one launch) against the reference's seeded eval_topn on the reference's own factors."""
+    g = load_golden(f"eval_topn_bias{int(bias)}.npz")
+    test = csr_from(g, "test")
+    m = WMF(num_items=test.shape[1], num_users=test.shape[0], dim=8, gamma=0.1, weighted=True, bias=bias)
+    m.users, m.items = g["users"], g["items"]
+    res = m.eval_topn(test_mat=test.copy(), topn=g["topn"], rand_sampled=int(g["rand_sampled"]), random_state=int(g["random_state"]))
+    got = np.array([res[f"Recall@{n}"] for n in g["topn"]], dtype=np.float64)
+    np.testing.assert_array_equal(got, g["recall"])
+    # the entry-by-entry route through rank() (what a model without the device hook takes) gives the same hits
+    np.random.seed(int(g["random_state"]))
+    hits = np.zeros(len(g["topn"]), dtype="float32")
+    from recmodel_amd.base_model import iter_rows_two_matrices
+    for elem in iter_rows_two_matrices(test, test):
+        hits += m.compute_hit(elem, rand_sampled=int(g["rand_sampled"]), topn=g["topn"])
+    np.testing.assert_array_equal((hits / int(g["n_test"])).astype(np.float64), g["recall"])
+    with pytest.raises(ValueError):
+        m.eval_topn(test_mat=test, topn=[1, 5])
+
+
+def test_rank_full_catalogue_on_device():
+    """rank over a 200 000-item catalogue: device scores + device sort vs NumPy on the same factors."""
+    from recmodel_amd import WMF
+    rng = np.random.default_rng(5)
+    n_items, n_users, k = 200_000, 64, 32
+    m = WMF(num_items=n_items, num_users=n_users, dim=k, gamma=0.1, weighted=True, bias=True)
+    m.users = rng.standard_normal((n_users, k + 1)).astype(np.float32)
+    m.items = rng.standard_normal((n_items, k + 1)).astype(np.float32)
+    cand = rng.permutation(n_items).astype(np.int64)
+    ref = orc.predict(m.users.astype(np.float64), m.items.astype(np.float64), [3], cand, True)
+    for topn in (10, 150_000, None):
+        got = m.rank(cand, 3, topn=topn)
+        want = orc.rank(m.users.astype(np.float64), m.items.astype(np.float64), cand, [3], topn=topn, bias=True)
+        assert len(got) == len(want) and len(set(got.tolist())) == len(got)
+        sc = dict(zip(cand.tolist(), ref.tolist()))
+        gs = np.array([sc[i] for i in got])
+        np.testing.assert_allclose(gs, [sc[i] for i in want], rtol=0, atol=2e-5)       # same scores position by position
+        assert (np.diff(gs) <= 2e-5).all()                                                  # best first
+    assert len(m.rank(cand[:5], 3, topn=50)) == 5                                            # topn beyond the list: all of it
+    with pytest.raises(IndexError):
+        m.rank(np.array([0, n_items]), 3, topn=1)
+
+
 def test_unweighted_branch_matches_reference_golden(WMF):
     g = load_golden("train_unweighted.npz")
     util = csr_from(g, "util")

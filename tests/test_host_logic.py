@@ -71,3 +71,38 @@ def test_gathered_positions_are_a_bijection_and_chunk_contiguous(world, chunks):
             np.testing.assert_array_equal(pos[mine[j]], world * s_c + r * len_c + (j - s_c))
     if world == 1:
         np.testing.assert_array_equal(pos, ids)
+
+
+def test_eval_topn_host_route_matches_reference_golden():
+    """RecModel.eval_topn for a model WITHOUT the device hook (entry-by-entry rank(), like the reference),
+    and with a hook fed by the pre-drawn candidates: both reproduce the reference's seeded Recall@N."""
+    from conftest import csr_from, load_golden
+    from oracle import wmf_oracle as orc
+    from recmodel_amd.base_model import RecModel
+    g = load_golden("eval_topn_bias1.npz")
+    test = csr_from(g, "test")
+
+    class HostModel(RecModel):
+        num_items = test.shape[1]
+
+        def rank(self, items, users, topn=None):
+            return orc.rank(g["users"], g["items"], items, users, topn=topn, bias=True)
+
+    res = HostModel().eval_topn(test_mat=test.copy(), topn=g["topn"], rand_sampled=int(g["rand_sampled"]),
+                                random_state=int(g["random_state"]))
+    np.testing.assert_array_equal(np.array([res[f"Recall@{n}"] for n in g["topn"]], dtype=np.float64), g["recall"])
+
+    class HookModel(HostModel):
+        def _hit_counts(self, pair_user, pair_item, pair_row, candidates, slot, topn):
+            hits = np.zeros(len(topn), dtype=np.int64)
+            for u, it, row in zip(pair_user, pair_item, pair_row):
+                cand = candidates[row].copy()
+                cand[slot[row]] = it
+                s = orc.predict(g["users"], g["items"], [u], cand, True)
+                higher = int((np.delete(s, slot[row]) > s[slot[row]]).sum())
+                hits += higher < topn
+            return hits
+
+    res = HookModel().eval_topn(test_mat=test.copy(), topn=g["topn"], rand_sampled=int(g["rand_sampled"]),
+                                random_state=int(g["random_state"]))
+    np.testing.assert_array_equal(np.array([res[f"Recall@{n}"] for n in g["topn"]], dtype=np.float64), g["recall"])

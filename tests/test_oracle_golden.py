@@ -122,3 +122,17 @@ def test_c_restatement_matches_reference_golden(bias):
     step = orc.recompute_factors_bias if bias else orc.recompute_factors
     np.testing.assert_allclose(c_oracle.half_step(g["items0"], C, 0.1, bias), step(g["items0"], C, 0.1, out_dtype="float64"),
                                rtol=rtol, atol=max(atol, 5e-6))
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_eval_topn_matches_reference_golden(bias):
+    """Seeded Recall@N (base_model.py:100-148): same np.random draws, same ranking, same hit counts."""
+    g = load_golden(f"eval_topn_bias{int(bias)}.npz")
+    test = csr_from(g, "test")
+    res, hits = orc.eval_topn(g["users"], g["items"], test, g["topn"], rand_sampled=int(g["rand_sampled"]),
+                              random_state=int(g["random_state"]), bias=bias, return_hits=True)
+    got = np.array([res[f"Recall@{n}"] for n in g["topn"]], dtype=np.float64)
+    np.testing.assert_array_equal(got, g["recall"])
+    assert hits.sum() > 0 and (np.diff(hits) >= 0).all()          # Recall@1 <= Recall@5 <= Recall@10
+    with pytest.raises(ValueError):
+        orc.eval_topn(g["users"], g["items"], test, [1, 5], rand_sampled=40)
