@@ -66,10 +66,43 @@ def cpu_baseline(cfg_name, user_rows, item_rows, users_f, k, bias, gamma, n_item
         step(users_f, CT, gamma)
         t_i = time.perf_counter() - t0
     rows = C.shape[0] + CT.shape[0]
-    return {"value": rows / (t_u + t_i), "unit": "row-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{cfg_name}: first {C.shape[0]} user rows ({C.nnz} nnz, {t_u:.1f}s) + first {CT.shape[0]} item rows "
-                      f"({CT.nnz} nnz, {t_i:.1f}s) of the same matrix, NumPy per-row loop, 1 BLAS thread",
-            "host_cpus": os.cpu_count()}
+    out = {"value": rows / (t_u + t_i), "unit": "row-updates/s", "cores": 1, "kind": "port",
+           "sample": f"{cfg_name}: first {C.shape[0]} user rows ({C.nnz} nnz, {t_u:.1f}s) + first {CT.shape[0]} item rows "
+                     f"({CT.nnz} nnz, {t_i:.1f}s) of the same matrix, NumPy per-row loop, 1 BLAS thread",
+           "host_cpus": os.cpu_count()}
+    # the "fair" CPU figure of SURVEY.md 8(d): the oracle's C restatement (float64, own LU) with OpenMP on every
+    # host core, same sample
+    try:
+        from oracle import c_oracle
+        threads = c_oracle.set_threads(len(os.sched_getaffinity(0)))   # the CPUs this process may run on
+        t0 = time.perf_counter()
+        c_oracle.half_step(items, C, gamma, bias)
+        c_oracle.half_step(users_f, CT, gamma, bias)
+        t_c = time.perf_counter() - t0
+        out["all_cores"] = {"value": rows / t_c, "unit": "row-updates/s", "cores": threads, "kind": "port",
+                            "sample": f"same rows through oracle/wmf_oracle.c (OpenMP, {threads} threads, float64), {t_c:.2f}s"}
+    except Exception as exc:                         # library not built on this box: say so, never substitute
+        out["all_cores"] = {"error": str(exc)}
+    return out
+
+
+def host_boundary(user_rows, k, bias, gamma, n_items):
+    """Rows/s through the HOST entry point (wmf_recompute_factors_host: host CSR + host factors in, host factors out,
+    one half step, including the PCIe transfers and the plan) -- what a caller pays who keeps nothing on the device.
+    Never the headline value."""
+    from oracle import wmf_oracle as orc
+    from recmodel_amd import WMF
+    C = user_rows.astype(np.float32)
+    C.data = orc.confidence_transform(C.data.astype(np.float64)).astype(np.float32)
+    m = WMF(num_items=n_items, num_users=C.shape[0], dim=k, gamma=gamma, weighted=True, bias=bias)
+    step = m.recompute_factors_bias if bias else m.recompute_factors
+    step(m.items, C, gamma)                                         # warm-up (library load, first launches)
+    t0 = time.perf_counter()
+    step(m.items, C, gamma)
+    dt = time.perf_counter() - t0
+    mb = (C.nnz * 8 + C.shape[0] * 8 + (n_items + C.shape[0]) * m.items.shape[1] * 4) / 1e6
+    return {"value": C.shape[0] / dt, "unit": "row-updates/s", "rows": int(C.shape[0]), "seconds": dt,
+            "pcie_megabytes": mb, "note": "one user half step through wmf_recompute_factors_host, PCIe-inclusive"}
 
 
 def measured_traffic(config, slot, f, ld):
@@ -241,6 +274,7 @@ def main():
         else:                                                    # timing does not depend on the values
             users_f = np.random.default_rng(0).random((n_users, eng.f), dtype=np.float32)
         out["cpu_baseline"] = cpu_baseline(args.config, user_rows, item_rows, users_f, k, bias, gamma, n_items)
+        out["host_boundary"] = host_boundary(user_rows, k, bias, gamma, n_items)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -19,6 +19,11 @@ def _load():
     return _lib
 
 
+def set_threads(n):
+    """OpenMP threads for the following calls; returns the number in effect."""
+    return int(_load().wmf_oracle_set_threads(ctypes.c_int(int(n))))
+
+
 def half_step(Y, C, lam, bias=False):
     """float64 [n, f] result of recompute_factors[_bias](Y, C, lam) computed in double (all host cores)."""
     lib = _load()

@@ -12,6 +12,7 @@
  * Build: make -C oracle   (gcc -O2 -fopenmp -shared -fPIC)
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -50,6 +51,12 @@ static int lu_solve(double* A, double* b, int f) {
 /* X[n, f] (double) = recompute_factors[_bias](Y[m, f] float32, CSR(indptr int64, indices int32,
  * values double), lambda).  bias != 0: column 0 of Y is the fixed side's bias (wmf_model.py:328-343).
  * Returns the number of singular rows (their output is left at 0). */
+/* number of OpenMP threads the next calls use; returns the value in effect */
+int wmf_oracle_set_threads(int n) {
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+}
+
 int wmf_oracle_half_step(const float* Y, int64_t m, int f, int bias, const int64_t* indptr, const int32_t* indices,
                          const double* values, int64_t n, double lambda, double* X) {
     double* G = (double*)calloc((size_t)f * f, sizeof(double));
@@ -57,11 +64,23 @@ int wmf_oracle_half_step(const float* Y, int64_t m, int f, int bias, const int64
     float* bvec = (float*)calloc((size_t)m, sizeof(float));
     memcpy(Yt, Y, (size_t)m * f * sizeof(float));
     if (bias) for (int64_t r = 0; r < m; ++r) { bvec[r] = Yt[r * f]; Yt[r * f] = 1.0f; }
-    for (int64_t r = 0; r < m; ++r)
-        for (int a = 0; a < f; ++a) {
-            double ya = Yt[r * f + a];
-            for (int c = 0; c < f; ++c) G[a * f + c] += ya * (double)Yt[r * f + c];
+    /* Gramian: per-thread partial sums over blocks of rows, added in thread order */
+#pragma omp parallel
+    {
+        double* Gt = (double*)calloc((size_t)f * f, sizeof(double));
+#pragma omp for schedule(static)
+        for (int64_t r = 0; r < m; ++r)
+            for (int a = 0; a < f; ++a) {
+                double ya = Yt[r * f + a];
+                for (int c = 0; c < f; ++c) Gt[a * f + c] += ya * (double)Yt[r * f + c];
+            }
+#pragma omp for ordered schedule(static, 1)
+        for (int t = 0; t < omp_get_num_threads(); ++t) {
+#pragma omp ordered
+            for (int e = 0; e < f * f; ++e) G[e] += Gt[e];
         }
+        free(Gt);
+    }
     for (int a = 0; a < f; ++a) G[a * f + a] += lambda;
     int bad = 0;
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : bad)
