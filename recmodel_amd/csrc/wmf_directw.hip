@@ -4,16 +4,18 @@
 //   g_u = (I + V_u^T D V_u)^-1 V_u^T p          (RecModel/wmf_model.py:233-239 in whitened coordinates)
 //
 // Tile (bi, bj), bi <= bj, of B = I + V^T D V is one 16 x 16 accumulator: lane (r = l & 15, q = l >> 4)
-// holds B[16 bi + 4q + reg][16 bj + r].  The right-hand side is block column NFB.  One wave per SIMD
-// (up to 512 registers), four independent waves per CU.
+// holds B[16 bi + 4q + reg][16 bj + r].  The right-hand side never becomes a tile: f32 MFMA and the VALU share one
+// pipe on gfx950, and a vector riding in a 16 x 16 tile would use 1/16 of each MFMA.  It is
+// kept as NFB registers y[fb] = (V^T p)[16 fb + lane & 15] and updated with plain FMAs.
 //   A. entries stream from HBM straight into operand registers (lane loads V[idx_{4s+q}][16 fb + r]),
-//      one 16-entry group ahead:  tile(bi,bj) += frag[bi]^T (w frag[bj]),  tile(bi,NFB) += frag[bi]^T (p in col 0).
+//      one 16-entry group ahead:  tile(bi,bj) += frag[bi]^T (w frag[bj]),  y[bi] += p frag[bi].
 //   C. block elimination without square roots (B = U^T D U, D_p = the pivot blocks):
 //        X   = inverse of the diagonal tile -- a symmetric tile in accumulator layout IS the row-distributed
 //              layout of the Gauss-Jordan sweep of wmf_solve.hip, so it is inverted in place with 16
 //              v_fmac_dpp steps, and the result is already the MFMA A operand;
 //        W_pj = X B_pj  : four MFMAs with the tile's own registers as the B operand (k = 4q + reg);
-//        B_ij -= B_pi^T W_pj : both operands from a two-panel LDS buffer (originals and W), in place.
+//        B_ij -= B_pi^T W_pj : both operands from a two-panel LDS buffer (originals and W), in place;
+//        w_p  = X y_p (DPP row sums), y_i -= B_pi^T w_p with the A operands the MFMAs just loaded.
 //   D. g_p = w_p - sum_{j>p} W_pj g_j with DPP row sums; no triangular solves are left.
 // A non-positive pivot (system not positive definite: possible with biases) bounces the row to the
 // pivoted LU kernel.
@@ -44,14 +46,17 @@ struct DwCfg {
 };
 
 template <int NFB>
-__device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for bj = bi .. NFB"
-    return bi * (NFB + 1) - (bi * (bi - 1)) / 2 + (bj - bi);
+__device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for bj = bi .. NFB - 1"
+    return bi * NFB - (bi * (bi - 1)) / 2 + (bj - bi);
 }
 
 // MODE 0: one wave per row (accumulate + eliminate).
 // Rows with more than WMF_HEAVY_T entries are split (power-law degrees):
 // MODE 1: one wave per SEGMENT of such a row: accumulate its WMF_SEG entries, store the partial tiles;
 // MODE 2: one wave per heavy row: add the partial tiles of its segments in order, then eliminate.
+// floats per segment in the partial buffer of split rows: the tiles [tile][reg][lane], then y [fb][lane]
+#define WMF_DW_PARTIAL(NFB) (((NFB) * ((NFB) + 1) / 2 * 4 + (NFB)) * 64)
+
 template <int NFB, int MODE>
 __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                               const float* __restrict__ V, const float* __restrict__ biasv,
@@ -62,10 +67,11 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                                                               int32_t* __restrict__ fb_count, int dbg,
                                                               const int64_t* __restrict__ seg_lo, const int32_t* __restrict__ seg_d,
                                                               const int32_t* __restrict__ seg_first, float* __restrict__ partial) {
-    constexpr int NT = NFB * (NFB + 1) / 2 + NFB;
+    constexpr int NT = NFB * (NFB + 1) / 2;
     constexpr int GS = DwCfg<NFB>::GS;                           // MFMA k-steps (4 entries each) per pipelined group
-    __shared__ __attribute__((aligned(16))) float Pan1[(NFB + 1) * 320];     // original tiles of block row p
-    __shared__ __attribute__((aligned(16))) float Pan2[(NFB + 1) * 320];     // W tiles of block row p
+    __shared__ __attribute__((aligned(16))) float Pan1[NFB * 320];           // original tiles of block row p
+    __shared__ __attribute__((aligned(16))) float Pan2[NFB * 320];           // W tiles of block row p
+    __shared__ __attribute__((aligned(16))) float Wv[NFB * 16];              // w_p = X_p y_p, kept for the backward pass
     const int lane = threadIdx.x;
     const int r = lane & 15, q = lane >> 4;
     int baddr[4];
@@ -126,7 +132,6 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                     for (int bi = 0; bi < NFB; ++bi) {
 #pragma unroll
                         for (int bj = bi; bj < NFB; ++bj, ++tt) acc[tt] = WMF_MFMA16(st.fr[S][t][bi], fw[bj], acc[tt]);
-                        ++tt;                                    // slot of the rhs tile (bi, NFB)
                     }
                 }
             }
@@ -144,34 +149,28 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                 (step(std::integral_constant<int, Ss>{}, G0 + Ss), ...);
             }(std::make_integer_sequence<int, DEPTH>{});
         }
-        // rhs[16 fb + r] on every lane (r, *), then into column 0 of the rhs tiles: lane (0, q) needs rows 4q + reg
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) {
-            racc[fb] += __shfl_xor(racc[fb], 16);
-            racc[fb] += __shfl_xor(racc[fb], 32);
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float v = __shfl(racc[fb], 4 * q + reg);
-                acc[tile_w<NFB>(fb, NFB)][reg] = (r == 0) ? v : 0.f;
-            }
-        }
+        // racc[fb] = this lane's share (its q) of y[16 fb + r]; the four shares are added when block fb becomes the pivot
         if (itn < count) prime(lon, dn);                         // next row's first loads fly during the elimination
         if constexpr (MODE == 1) {                               // partial tiles of this segment: [tile][reg][lane]
-            float* out = partial + it * (int64_t)(NT * 256);
+            float* out = partial + it * (int64_t)WMF_DW_PARTIAL(NFB);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) out[(t * 4 + reg) * 64 + lane] = acc[t][reg];
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) out[(NT * 4 + fb) * 64 + lane] = racc[fb];
             u = un; lo = lon; d = dn;
             continue;
         }
         if constexpr (MODE == 2) {                               // sum the segments of heavy row `it` in a fixed order
             for (int sgm = seg_first[it]; sgm < seg_first[it + 1]; ++sgm) {
-                const float* in = partial + sgm * (int64_t)(NT * 256);
+                const float* in = partial + sgm * (int64_t)WMF_DW_PARTIAL(NFB);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) acc[t][reg] += in[(t * 4 + reg) * 64 + lane];
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) racc[fb] += in[(NT * 4 + fb) * 64 + lane];
             }
         }
 
@@ -187,10 +186,18 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
             for (int p = 0; p < NFB; ++p) {
                 f32x4 X = acc[tile_w<NFB>(p, p)];
                 gj_inv_sweep(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
+                // y_p[r] complete (its four q shares added), then w_p = X y_p: lane (r, q) has X[4q + reg][r] (X is
+                // symmetric), so the products summed over the 16 lanes of a DPP row give w_p[4q + reg] on the whole row
+                float yp = racc[p];
+                yp += __shfl_xor(yp, 16);
+                yp += __shfl_xor(yp, 32);
+                float wv0 = X[0] * yp, wv1 = X[1] * yp, wv2 = X[2] * yp, wv3 = X[3] * yp;
+                wmf_row16_sum4(wv0, wv1, wv2, wv3);
+                if (r == 0) *reinterpret_cast<float4*>(&Wv[16 * p + 4 * q]) = make_float4(wv0, wv1, wv2, wv3);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int j = p + 1; j <= NFB; ++j) {
+                for (int j = p + 1; j < NFB; ++j) {
                     const int t = tile_w<NFB>(p, j);
                     f32x4 n = f32x4{0.f, 0.f, 0.f, 0.f};
                     n = WMF_MFMA16(X[0], acc[t][0], n); n = WMF_MFMA16(X[1], acc[t][1], n);
@@ -209,8 +216,10 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                     float a[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a[e] = -Pan1[i * 320 + (4 * q + e) * 20 + r];
+                    // y_i[r] -= sum_rows B_pi[row][r] w_p[row]: this lane's rows are 4q + e, a[e] = -B_pi[4q + e][r]
+                    racc[i] += a[0] * wv0 + a[1] * wv1 + a[2] * wv2 + a[3] * wv3;
 #pragma unroll
-                    for (int j = i; j <= NFB; ++j) {
+                    for (int j = i; j < NFB; ++j) {
                         const int t = tile_w<NFB>(i, j);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[t] = WMF_MFMA16(a[e], Pan2[j * 320 + (4 * q + e) * 20 + r], acc[t]);
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                 float gsel = 0.f;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const float w = wmf_dpp<0x150>(acc[tile_w<NFB>(p, NFB)][reg]);       // column 0 of the rhs tile -> whole row
+                    const float w = Wv[16 * p + 4 * q + reg];                             // w_p[4q + reg]
                     const float gv = w - ((p + 1 < NFB) ? wmf_row16_sum(s[reg]) : 0.f);  // g_p[4q + reg] on every lane (., q)
                     gsel = ((r & 3) == reg) ? gv : gsel;
                 }
