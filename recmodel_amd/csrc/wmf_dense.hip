@@ -394,13 +394,19 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
     constexpr int KP = 16 * NFB;          // padded K (rows of W) and padded N (cols of W)
     constexpr int LDW = KP + 4;           // 4 mod 8 since KP is a multiple of 16
     const int tid = threadIdx.x;
-    if constexpr (W_IN_LDS) {
-        for (int e = tid; e < KP * LDW; e += 512) {
-            const int a = e / LDW, b = e % LDW;
-            Wl[e] = (a < f && b < f) ? W[a * ld + b] : 0.f;
-        }
-        __syncthreads();
+    // nz[kb * NFB + nb] != 0 iff the 16 x 16 tile (kb, nb) of W has a non-zero entry.  Both matrices this kernel is
+    // used with are triangular (L^-T, L^-1), so 36 of 81 tile products at f = 129 are skipped -- found from the data,
+    // any W stays correct.
+    __shared__ int nz[NFB * NFB];
+    for (int e = tid; e < NFB * NFB; e += 512) nz[e] = 0;
+    __syncthreads();
+    for (int e = tid; e < KP * LDW; e += 512) {
+        const int a = e / LDW, b = e % LDW;
+        const float v = (a < f && b < f) ? W[a * ld + b] : 0.f;
+        if constexpr (W_IN_LDS) Wl[e] = v;
+        if (v != 0.f && b < KP) nz[(a >> 4) * NFB + (b >> 4)] = 1;    // benign race: every writer stores 1
     }
+    __syncthreads();
     const int lane = tid & 63, wv = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int nch = ld >> 2;
@@ -422,6 +428,9 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
                 if (!(rok && c + 4 < nch)) xn = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             const int k0 = 4 * c;
+            int tnz[NFB];
+#pragma unroll
+            for (int nb = 0; nb < NFB; ++nb) tnz[nb] = __builtin_amdgcn_readfirstlane(nz[t * NFB + nb]);
             float xe[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (k0 + e >= f) xe[e] = 0.f;
@@ -430,10 +439,11 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
                 xe[0] = rok ? 1.f : 0.f;
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = k0 + e;
+            for (int nb = 0; nb < NFB; ++nb) {
+                if (!tnz[nb]) continue;                      // wave-uniform: an all-zero tile of W
 #pragma unroll
-                for (int nb = 0; nb < NFB; ++nb) {
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + e;
                     float b;
                     if constexpr (W_IN_LDS) {
                         b = Wl[k * LDW + 16 * nb + r];

@@ -35,13 +35,19 @@
 #ifndef WMF_DW_DEPTH
 #define WMF_DW_DEPTH 3
 #endif
+#ifndef WMF_DW_DEPTH_WIDE
+#define WMF_DW_DEPTH_WIDE 3
+#endif
+#ifndef WMF_DW_GS_WIDE
+#define WMF_DW_GS_WIDE 2
+#endif
 #ifndef WMF_DW_OCC4
 #define WMF_DW_OCC4 3
 #endif
 template <int NFB>
 struct DwCfg {
-    static constexpr int GS = (NFB <= 4) ? WMF_DW_GS : 2;
-    static constexpr int DEPTH = (NFB <= 4) ? WMF_DW_DEPTH : 3;
+    static constexpr int GS = (NFB <= 4) ? WMF_DW_GS : WMF_DW_GS_WIDE;
+    static constexpr int DEPTH = (NFB <= 4) ? WMF_DW_DEPTH : WMF_DW_DEPTH_WIDE;
     static constexpr int OCC = NFB <= 4 ? WMF_DW_OCC4 : (NFB <= 6 ? 2 : 1);      // waves per SIMD
 };
 

@@ -134,6 +134,9 @@ def coo_to_csr(rows, cols, vals, n_rows):
     return indptr, cols[order].to(torch.int32), vals[order]
 
 
+MIN_CHUNK_ROWS = 32768          # default chunking never makes chunks smaller than this
+
+
 def gathered_positions(ids, world, rows_per_rank, chunk_len):
     """Row of id ``ids`` in a chunk-major gathered matrix (module docstring).  Works on ints and tensors."""
     j = ids // world
@@ -163,10 +166,16 @@ class AlsEngine:
         W = self.world
         self.rpr = {s: (self.n[s] + W - 1) // W for s in self.n}            # rows per rank (padded)
         self.n_local = {s: len(range(self.rank, self.n[s], W)) for s in self.n}
+        auto_chunks = chunks is None and "WMF_CHUNKS" not in os.environ
         if chunks is None:
             chunks = int(os.environ.get("WMF_CHUNKS", "4")) if W > 1 else 1
-        # chunk c of a side = local rows [c * chunk_len, min((c + 1) * chunk_len, rows_per_rank))
-        self.chunk_len = {s: max(1, (self.rpr[s] + max(1, int(chunks)) - 1) // max(1, int(chunks))) for s in self.n}
+        # chunk c of a side = local rows [c * chunk_len, min((c + 1) * chunk_len, rows_per_rank)).  A side whose block is
+        # small is not cut when the chunk count is the default: its gather is cheap, and a few thousand heavy rows per
+        # launch would leave most of the 3000 resident waves of the row kernels idle in the last round.
+        want = {s: max(1, int(chunks)) for s in self.n}
+        if auto_chunks:
+            want = {s: max(1, min(want[s], self.rpr[s] // MIN_CHUNK_ROWS)) for s in self.n}
+        self.chunk_len = {s: max(1, (self.rpr[s] + want[s] - 1) // want[s]) for s in self.n}
         self.chunk_bounds = {s: [(lo, min(self.chunk_len[s], self.rpr[s] - lo))
                                  for lo in range(0, max(self.rpr[s], 1), self.chunk_len[s]) if lo < self.rpr[s]]
                              for s in self.n}

@@ -36,7 +36,8 @@ def _worker(rank, world, port, bias, out_path):
         n_users, n_items, dim = 203, 57, 6           # not multiples of the world size: padding rows exist
         indptr, indices, counts = synth.make_counts(n_users, n_items, 5, seed=11)
         values = (10 * torch.log(1 + counts)).to(torch.float32)
-        eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cpu", kernels=NumpyKernels())
+        eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cpu", kernels=NumpyKernels(), chunks=4)
+        assert len(eng.csr_chunks) == 0 and len(eng.chunk_bounds["users"]) == 4
         assert eng.world == world and eng.rank == rank
         eng.set_interactions(indptr, indices, values)
         # every stored entry lands on exactly one rank, in both orientations

@@ -35,7 +35,7 @@ def _worker(rank, world, port, bias, out_path):
         n_users, n_items, dim = 1203, 257, 24
         indptr, indices, counts = synth.make_counts(n_users, n_items, 9, seed=11)
         values = (10 * torch.log(1 + counts)).to(torch.float32)
-        eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cuda:0")
+        eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cuda:0", chunks=3)
         eng.set_interactions(indptr, indices, values)
         eng.set_factors("items", orc.init_items(n_items, dim, bias))
         for _ in range(2):

@@ -106,3 +106,15 @@ def test_eval_topn_host_route_matches_reference_golden():
     res = HookModel().eval_topn(test_mat=test.copy(), topn=g["topn"], rand_sampled=int(g["rand_sampled"]),
                                 random_state=int(g["random_state"]))
     np.testing.assert_array_equal(np.array([res[f"Recall@{n}"] for n in g["topn"]], dtype=np.float64), g["recall"])
+
+
+def test_default_chunking_leaves_small_sides_whole():
+    """With the default chunk count a side is only cut into chunks of at least MIN_CHUNK_ROWS rows (engine.py);
+    an explicit count is honoured as given."""
+    from fake_kernels import NumpyKernels             # tests/ is on sys.path (conftest lives there)
+    from recmodel_amd import engine
+    e = engine.AlsEngine(5 * engine.MIN_CHUNK_ROWS, 1000, 4, False, 0.1, device="cpu", kernels=NumpyKernels())
+    assert e.world == 1 and len(e.chunk_bounds["users"]) == 1                      # one rank: never chunked by default
+    e = engine.AlsEngine(5 * engine.MIN_CHUNK_ROWS, 1000, 4, False, 0.1, device="cpu", kernels=NumpyKernels(), chunks=3)
+    assert len(e.chunk_bounds["users"]) == 3 and len(e.chunk_bounds["items"]) == 3
+    assert sum(n for _, n in e.chunk_bounds["items"]) == 1000
