@@ -46,6 +46,19 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_share():
+    """CPUs this process can actually use: the cgroup quota when there is one (a GPU box hands each job a share
+    of a large host), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(cfg_name, user_rows, item_rows, users_f, k, bias, gamma, n_items):
     """The oracle's NumPy restatement of recompute_factors[_bias] (same per-row gather / dot / solve
     structure as RecModel/wmf_model.py:220-239, one thread) on row samples of the same matrices:
@@ -74,7 +87,7 @@ def cpu_baseline(cfg_name, user_rows, item_rows, users_f, k, bias, gamma, n_item
     # host core, same sample
     try:
         from oracle import c_oracle
-        threads = c_oracle.set_threads(len(os.sched_getaffinity(0)))   # the CPUs this process may run on
+        threads = c_oracle.set_threads(cpu_share())
         t0 = time.perf_counter()
         c_oracle.half_step(items, C, gamma, bias)
         c_oracle.half_step(users_f, CT, gamma, bias)

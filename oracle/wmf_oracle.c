@@ -83,13 +83,15 @@ int wmf_oracle_half_step(const float* Y, int64_t m, int f, int bias, const int64
     }
     for (int a = 0; a < f; ++a) G[a * f + a] += lambda;
     int bad = 0;
-#pragma omp parallel for schedule(dynamic, 64) reduction(+ : bad)
+#pragma omp parallel reduction(+ : bad)
+    {
+    double* A = (double*)malloc((size_t)f * f * sizeof(double));   /* one scratch matrix per thread */
+#pragma omp for schedule(dynamic, 64)
     for (int64_t u = 0; u < n; ++u) {
         double* x = X + u * f;
         memset(x, 0, (size_t)f * sizeof(double));
         int64_t lo = indptr[u], hi = indptr[u + 1];
         if (hi == lo) continue;
-        double* A = (double*)malloc((size_t)f * f * sizeof(double));
         memcpy(A, G, (size_t)f * f * sizeof(double));
         for (int64_t j = lo; j < hi; ++j) {
             const float* y = Yt + (int64_t)indices[j] * f;
@@ -101,7 +103,8 @@ int wmf_oracle_half_step(const float* Y, int64_t m, int f, int bias, const int64
             }
         }
         if (lu_solve(A, x, f)) { memset(x, 0, (size_t)f * sizeof(double)); bad += 1; }
-        free(A);
+    }
+    free(A);
     }
     free(G); free(Yt); free(bvec);
     return bad;
