@@ -103,10 +103,9 @@ def host_boundary(user_rows, k, bias, gamma, n_items):
     """Rows/s through the HOST entry point (wmf_recompute_factors_host: host CSR + host factors in, host factors out,
     one half step, including the PCIe transfers and the plan) -- what a caller pays who keeps nothing on the device.
     Never the headline value."""
-    from oracle import wmf_oracle as orc
     from recmodel_amd import WMF
     C = user_rows.astype(np.float32)
-    C.data = orc.confidence_transform(C.data.astype(np.float64)).astype(np.float32)
+    C.data = (10.0 * np.log(1.0 + C.data.astype(np.float64))).astype(np.float32)      # alpha = 10, beta = 1, 'log'
     m = WMF(num_items=n_items, num_users=C.shape[0], dim=k, gamma=gamma, weighted=True, bias=bias)
     step = m.recompute_factors_bias if bias else m.recompute_factors
     step(m.items, C, gamma)                                         # warm-up (library load, first launches)
@@ -172,8 +171,8 @@ def main():
     values = counts.clone()
     eng.K.confidence_transform(values, 10.0, 1.0, 0)
     eng.set_interactions(indptr, indices, values)
-    from oracle import wmf_oracle as orc            # init only: the legacy-RNG draw of wmf_model.py:10-17
-    eng.set_factors("items", orc.init_items(n_items, k, bias))
+    from recmodel_amd import WMF                    # the package's own constructor draws the initial item factors
+    eng.set_factors("items", WMF(num_items=n_items, num_users=1, dim=k, gamma=gamma, weighted=True, bias=bias).items)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t0
 

@@ -287,9 +287,21 @@ class AlsEngine:
             torch.distributed.all_reduce(self.G, group=self.group)
         K.factorize(self.G, self.f, self.ld, self.gamma, self.W_white, self.W_unwhite, self.info, self.ws)
         V, bvec = self.V[fixed], self.bias_vec[fixed]
-        self._wait(fixed)
-        rows = self.n_local[fixed] if self.world == 1 else self.world * self.rpr[fixed]
-        K.row_transform(self.X[fixed], rows, self.f, self.ld, self.W_white, self.bias, V, bvec if self.bias else None)
+        if self.world == 1:
+            K.row_transform(self.X[fixed], self.n_local[fixed], self.f, self.ld, self.W_white, self.bias, V,
+                            bvec if self.bias else None)
+            return
+        # whiten chunk by chunk, each as soon as ITS all-gather has landed: the passes over the early chunks run while
+        # the later chunks are still on the wire (in-flight gathers complete in issue order)
+        pending, self._pending[fixed] = self._pending[fixed], []
+        done = len(self.chunk_bounds[fixed]) - len(pending)          # chunks whose gather was waited for earlier
+        W = self.world
+        for c, (lo, ln) in enumerate(self.chunk_bounds[fixed]):
+            if c >= done:
+                pending[c - done].wait()
+            rows = slice(W * lo, W * (lo + ln))
+            K.row_transform(self.X[fixed][rows], W * ln, self.f, self.ld, self.W_white, self.bias, V[rows],
+                            bvec[rows] if self.bias else None)
 
     def update(self, side):
         """Solve every local row of ``side`` against the prepared fixed side.  wmf_model.py:220-239."""
