@@ -396,3 +396,37 @@ def test_very_heavy_rows_are_split_into_segments(WMF, k, bias):
     rel, _ = worst_row(got, want)
     assert fro(got, want) <= HALF_FRO and rel <= HALF_ROW, (fro(got, want), rel)
     assert np.array_equal(got, step_g(model.items, C, 0.1))          # fixed combination order: bitwise reproducible
+
+
+# ------------------------------------------------------------------ degenerate shapes
+@pytest.mark.parametrize("bias", [False, True])
+def test_degenerate_shapes(WMF, bias):
+    """Nothing stored at all, a single user, a single item, k = 1: the reference handles them (solve(G, 0) = 0,
+    1 x 1 systems), so must the kernels."""
+    step_o = orc.recompute_factors_bias if bias else orc.recompute_factors
+    rng = np.random.default_rng(3)
+    for n, m_items, k, dens in ((5, 7, 4, 0.0), (1, 9, 3, 0.6), (6, 1, 2, 0.7), (40, 30, 1, 0.3), (3, 200, 16, 1.0)):
+        C = sp.random(n, m_items, density=dens, random_state=int(rng.integers(1 << 30)), format="csr", dtype=np.float32)
+        C.data = (1 + 10 * C.data).astype(np.float32)
+        model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=bias)
+        step_g = model.recompute_factors_bias if bias else model.recompute_factors
+        want = step_o(model.items, as_f64(C), 0.1, out_dtype="float64")
+        got = step_g(model.items, C, 0.1)
+        assert got.shape == want.shape and got.dtype == np.float32
+        assert fro(got, want) <= HALF_FRO or np.abs(got - want).max() <= 1e-6, (n, m_items, k, dens, fro(got, want))
+        if C.nnz == 0:
+            assert not got.any()
+    # a full training run on a matrix with an empty user, an empty item and one dense row
+    C = sp.random(30, 20, density=0.2, random_state=7, format="lil", dtype=np.float64)
+    C[9, :] = 3
+    C[4, :] = 0
+    C[:, 6] = 0
+    C = sp.csr_matrix(C)
+    C.data = np.ceil(C.data * 4)
+    model = WMF(num_items=20, num_users=30, dim=5, gamma=0.1, weighted=True, bias=bias)
+    last = model.train(utility_mat=C.copy(), count_mat=C.copy(), iterations=3, eval_mat=C.copy(), stopping_rounds=5)
+    o_last, _, o_users, o_items = orc.train(20, 30, 5, 0.1, C.copy(), 3, C.copy(), count_mat=C.copy(), bias=bias, stopping_rounds=5)
+    assert last == o_last
+    assert fro(model.users, o_users.astype(np.float64)) <= TRAIN_FRO and fro(model.items, o_items.astype(np.float64)) <= TRAIN_FRO
+    if not bias:
+        assert not model.users[4].any() and not model.items[6].any()     # rows without stored entries are exactly zero
