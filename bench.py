@@ -152,7 +152,7 @@ def main():
     n_users_1, n_items, dbar, k, bias = synth.CONFIGS[args.config]
     n_users = n_users_1 * world                     # weak scaling over users
     gamma = 0.1
-    seed = 1993 + {"cfg1": 1, "cfg2": 2, "cfg3": 3, "cfg5s": 5, "tiny": 9}[args.config]
+    seed = 1993 + {"cfg1": 1, "cfg2": 2, "cfg3": 3, "cfg4": 3, "cfg5s": 5, "tiny": 9}[args.config]
 
     # ---- synthetic workload, generated on the GPU (identical on every rank) -----------------
     t0 = time.perf_counter()

@@ -19,6 +19,14 @@
 //   D. g_p = w_p - sum_{j>p} W_pj g_j with DPP row sums; no triangular solves are left.
 // A non-positive pivot (system not positive definite: possible with biases) bounces the row to the
 // pivoted LU kernel.
+//
+// BORDER (f = 16 NFB + 1: k a multiple of 16 plus the bias column).  A ninth block column would hold ONE real
+// column and cost 9 of 45 tiles in every k-step; instead the last feature is a border of the NFB-block system,
+//     [ A   b ] [ g ]   [ y ]          A, y: the tiles and the vector above,  b = column f-1,  c = B[f-1][f-1],
+//     [ b^T c ] [ t ] = [ e ]
+// b rides through the elimination exactly like y (w^b_p = X_p b_p, b_i -= B_pi^T w^b_p), the last pivot is the
+// scalar  c - sum_p b_p^T w^b_p,  t = (e - sum_p b_p^T w^y_p) / pivot,  and the backward pass starts from
+// w^y_p - t w^b_p.  Measured at k = 128 + bias: the f = 128 kernel runs 38 ms where the nine-block one ran 50.
 #include "wmf_common.h"
 #include "wmf_internal.h"
 #include "wmf_stream.h"
@@ -41,6 +49,9 @@
 #ifndef WMF_DW_GS_WIDE
 #define WMF_DW_GS_WIDE 2
 #endif
+#ifndef WMF_DW_OCC8
+#define WMF_DW_OCC8 1
+#endif
 #ifndef WMF_DW_OCC4
 #define WMF_DW_OCC4 3
 #endif
@@ -48,7 +59,7 @@ template <int NFB>
 struct DwCfg {
     static constexpr int GS = (NFB <= 4) ? WMF_DW_GS : WMF_DW_GS_WIDE;
     static constexpr int DEPTH = (NFB <= 4) ? WMF_DW_DEPTH : WMF_DW_DEPTH_WIDE;
-    static constexpr int OCC = NFB <= 4 ? WMF_DW_OCC4 : (NFB <= 6 ? 2 : 1);      // waves per SIMD
+    static constexpr int OCC = NFB <= 4 ? WMF_DW_OCC4 : (NFB <= 6 ? 2 : (NFB <= 8 ? WMF_DW_OCC8 : 1));      // waves per SIMD
 };
 
 template <int NFB>
@@ -60,10 +71,11 @@ __device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for
 // Rows with more than WMF_HEAVY_T entries are split (power-law degrees):
 // MODE 1: one wave per SEGMENT of such a row: accumulate its WMF_SEG entries, store the partial tiles;
 // MODE 2: one wave per heavy row: add the partial tiles of its segments in order, then eliminate.
-// floats per segment in the partial buffer of split rows: the tiles [tile][reg][lane], then y [fb][lane]
-#define WMF_DW_PARTIAL(NFB) (((NFB) * ((NFB) + 1) / 2 * 4 + (NFB)) * 64)
+// floats per segment in the partial buffer of split rows: the tiles [tile][reg][lane], then y [fb][lane], then
+// (BORDER) b [fb][lane], c [lane], e [lane]
+#define WMF_DW_PARTIAL(NFB, BORDER) (((NFB) * ((NFB) + 1) / 2 * 4 + (NFB) + ((BORDER) ? (NFB) + 2 : 0)) * 64)
 
-template <int NFB, int MODE>
+template <int NFB, int MODE, bool BORDER>
 __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                               const float* __restrict__ V, const float* __restrict__ biasv,
                                                               const int64_t* __restrict__ indptr,
@@ -78,6 +90,7 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
     __shared__ __attribute__((aligned(16))) float Pan1[NFB * 320];           // original tiles of block row p
     __shared__ __attribute__((aligned(16))) float Pan2[NFB * 320];           // W tiles of block row p
     __shared__ __attribute__((aligned(16))) float Wv[NFB * 16];              // w_p = X_p y_p, kept for the backward pass
+    __shared__ __attribute__((aligned(16))) float Wb[BORDER ? NFB * 16 : 4]; // w^b_p = X_p b_p
     const int lane = threadIdx.x;
     const int r = lane & 15, q = lane >> 4;
     int baddr[4];
@@ -87,7 +100,7 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
     // Row pipeline (wmf_stream.h): factor rows are requested DEPTH groups ahead; the next row's first loads
     // are requested before this row's elimination starts.
     constexpr int DEPTH = DwCfg<NFB>::DEPTH;
-    using Stream = WmfRowStream<NFB, GS, DEPTH>;
+    using Stream = WmfRowStream<NFB + (BORDER ? 1 : 0), GS, DEPTH>;   // BORDER: one more (dword) block, lane r = 0 of it is the border feature
     Stream st;
     int u = 0, d = 0;
     int64_t lo = 0;
@@ -118,9 +131,12 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float racc[NFB];
+        float racc[NFB], bacc[BORDER ? NFB : 1];
+        float cacc = 0.f, eacc = 0.f;                            // border: c and e (this lane's q share; equal across r)
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) racc[fb] = 0.f;
+#pragma unroll
+        for (int fb = 0; fb < (BORDER ? NFB : 1); ++fb) bacc[fb] = 0.f;
 
         // ---- A (the rhs V^T p rides on the VALU and becomes block column NFB afterwards)
         auto step = [&](auto slot, int G) {
@@ -133,6 +149,14 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                     st.template mask_tail<S>(t, ld, r);
 #pragma unroll
                     for (int fb = 0; fb < NFB; ++fb) { fw[fb] = st.fr[S][t][fb] * st.w[S][t]; racc[fb] += st.fr[S][t][fb] * st.p[S][t]; }
+                    if constexpr (BORDER) {
+                        const float bf = wmf_dpp<0x150>(st.fr[S][t][NFB]);          // border feature of this lane's entry (row_newbcast:0)
+                        const float bw = bf * st.w[S][t];
+#pragma unroll
+                        for (int fb = 0; fb < NFB; ++fb) bacc[fb] += st.fr[S][t][fb] * bw;
+                        cacc += bf * bw;
+                        eacc += bf * st.p[S][t];
+                    }
                     int tt = 0;
 #pragma unroll
                     for (int bi = 0; bi < NFB; ++bi) {
@@ -158,25 +182,37 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
         // racc[fb] = this lane's share (its q) of y[16 fb + r]; the four shares are added when block fb becomes the pivot
         if (itn < count) prime(lon, dn);                         // next row's first loads fly during the elimination
         if constexpr (MODE == 1) {                               // partial tiles of this segment: [tile][reg][lane]
-            float* out = partial + it * (int64_t)WMF_DW_PARTIAL(NFB);
+            float* out = partial + it * (int64_t)WMF_DW_PARTIAL(NFB, BORDER);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) out[(t * 4 + reg) * 64 + lane] = acc[t][reg];
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb) out[(NT * 4 + fb) * 64 + lane] = racc[fb];
+            if constexpr (BORDER) {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) out[(NT * 4 + NFB + fb) * 64 + lane] = bacc[fb];
+                out[(NT * 4 + 2 * NFB) * 64 + lane] = cacc;
+                out[(NT * 4 + 2 * NFB + 1) * 64 + lane] = eacc;
+            }
             u = un; lo = lon; d = dn;
             continue;
         }
         if constexpr (MODE == 2) {                               // sum the segments of heavy row `it` in a fixed order
             for (int sgm = seg_first[it]; sgm < seg_first[it + 1]; ++sgm) {
-                const float* in = partial + sgm * (int64_t)WMF_DW_PARTIAL(NFB);
+                const float* in = partial + sgm * (int64_t)WMF_DW_PARTIAL(NFB, BORDER);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) acc[t][reg] += in[(t * 4 + reg) * 64 + lane];
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) racc[fb] += in[(NT * 4 + fb) * 64 + lane];
+                if constexpr (BORDER) {
+#pragma unroll
+                    for (int fb = 0; fb < NFB; ++fb) bacc[fb] += in[(NT * 4 + NFB + fb) * 64 + lane];
+                    cacc += in[(NT * 4 + 2 * NFB) * 64 + lane];
+                    eacc += in[(NT * 4 + 2 * NFB + 1) * 64 + lane];
+                }
             }
         }
 
@@ -200,6 +236,19 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                 float wv0 = X[0] * yp, wv1 = X[1] * yp, wv2 = X[2] * yp, wv3 = X[3] * yp;
                 wmf_row16_sum4(wv0, wv1, wv2, wv3);
                 if (r == 0) *reinterpret_cast<float4*>(&Wv[16 * p + 4 * q]) = make_float4(wv0, wv1, wv2, wv3);
+                float wb0 = 0.f, wb1 = 0.f, wb2 = 0.f, wb3 = 0.f;
+                if constexpr (BORDER) {
+                    float bp = bacc[p];
+                    bp += __shfl_xor(bp, 16);
+                    bp += __shfl_xor(bp, 32);
+                    wb0 = X[0] * bp; wb1 = X[1] * bp; wb2 = X[2] * bp; wb3 = X[3] * bp;
+                    wmf_row16_sum4(wb0, wb1, wb2, wb3);
+                    if (r == 0) *reinterpret_cast<float4*>(&Wb[16 * p + 4 * q]) = make_float4(wb0, wb1, wb2, wb3);
+                    // b_p^T w^b_p and b_p^T w^y_p: this q group's rows 4q + reg (b_p[row] sits in lane `row`)
+                    const float b0 = __shfl(bp, 4 * q), b1 = __shfl(bp, 4 * q + 1), b2 = __shfl(bp, 4 * q + 2), b3 = __shfl(bp, 4 * q + 3);
+                    cacc -= b0 * wb0 + b1 * wb1 + b2 * wb2 + b3 * wb3;
+                    eacc -= b0 * wv0 + b1 * wv1 + b2 * wv2 + b3 * wv3;
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -224,6 +273,7 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                     for (int e = 0; e < 4; ++e) a[e] = -Pan1[i * 320 + (4 * q + e) * 20 + r];
                     // y_i[r] -= sum_rows B_pi[row][r] w_p[row]: this lane's rows are 4q + e, a[e] = -B_pi[4q + e][r]
                     racc[i] += a[0] * wv0 + a[1] * wv1 + a[2] * wv2 + a[3] * wv3;
+                    if constexpr (BORDER) bacc[i] += a[0] * wb0 + a[1] * wb1 + a[2] * wb2 + a[3] * wb3;
 #pragma unroll
                     for (int j = i; j < NFB; ++j) {
                         const int t = tile_w<NFB>(i, j);
@@ -235,6 +285,14 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
         }
         // ---- D: g_p = w_p - sum_{j > p} W_pj g_j ; gb[j] = g_j[lane & 15] on every lane
         float gb[NFB];
+        float tb = 0.f;                                          // BORDER: the last unknown
+        if constexpr (BORDER) {
+            cacc += __shfl_xor(cacc, 16); cacc += __shfl_xor(cacc, 32);
+            eacc += __shfl_xor(eacc, 16); eacc += __shfl_xor(eacc, 32);
+            const float piv = 1.f + cacc;                       // identity + c - sum_p b_p^T w^b_p
+            if (!(piv > 1e-20f)) ok = false;
+            tb = eacc * __builtin_amdgcn_rcpf(piv);
+        }
         if (!(dbg & 1)) {
 #pragma unroll
             for (int p = NFB - 1; p >= 0; --p) {
@@ -248,7 +306,8 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                 float gsel = 0.f;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const float w = Wv[16 * p + 4 * q + reg];                             // w_p[4q + reg]
+                    float w = Wv[16 * p + 4 * q + reg];                                   // w_p[4q + reg]
+                    if constexpr (BORDER) w -= tb * Wb[16 * p + 4 * q + reg];
                     const float gv = w - ((p + 1 < NFB) ? wmf_row16_sum(s[reg]) : 0.f);  // g_p[4q + reg] on every lane (., q)
                     gsel = ((r & 3) == reg) ? gv : gsel;
                 }
@@ -263,6 +322,10 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                 const int c = Stream::real_col(p, r);            // undo the feature permutation of the row stream
                 if (c < ld) g[(int64_t)u * ld + c] = (c < f) ? gb[p] : 0.f;
             }
+            if constexpr (BORDER) {
+                const int c = 16 * NFB + r;                      // the border column and the padding behind it
+                if (c < ld) g[(int64_t)u * ld + c] = (r == 0) ? tb : 0.f;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -270,7 +333,7 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
     }
 }
 
-template <int NFB>
+template <int NFB, bool BORDER>
 static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
                                const int32_t* indices, const float* vals, int f, int ld, float* g, int dbg, hipStream_t st) {
     constexpr int waves_per_cu = 4 * DwCfg<NFB>::OCC;
@@ -278,18 +341,18 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
     const int32_t* rows = pl->rows[WMF_BIN_MFMA];
     const int64_t normal = pl->count[WMF_BIN_MFMA] - pl->heavy_count;
     if (normal > 0)
-        hipLaunchKernelGGL((solve_directw_kernel<NFB, 0>), dim3((unsigned)(normal < cap ? normal : cap)), dim3(64), 0, st, rows,
-                           normal, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
+        hipLaunchKernelGGL((solve_directw_kernel<NFB, 0, BORDER>), dim3((unsigned)(normal < cap ? normal : cap)), dim3(64), 0, st,
+                           rows, normal, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
                            nullptr, nullptr, nullptr, nullptr);
     if (pl->heavy_count > 0) {
         const int64_t nseg = pl->seg_total;
-        hipLaunchKernelGGL((solve_directw_kernel<NFB, 1>), dim3((unsigned)(nseg < cap ? nseg : cap)), dim3(64), 0, st, rows, nseg,
-                           V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg, pl->seg_lo,
+        hipLaunchKernelGGL((solve_directw_kernel<NFB, 1, BORDER>), dim3((unsigned)(nseg < cap ? nseg : cap)), dim3(64), 0, st, rows,
+                           nseg, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg, pl->seg_lo,
                            pl->seg_d, pl->seg_first, pl->partial);
         const int64_t nh = pl->heavy_count;
-        hipLaunchKernelGGL((solve_directw_kernel<NFB, 2>), dim3((unsigned)(nh < cap ? nh : cap)), dim3(64), 0, st, rows + normal,
-                           nh, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg, pl->seg_lo,
-                           pl->seg_d, pl->seg_first, pl->partial);
+        hipLaunchKernelGGL((solve_directw_kernel<NFB, 2, BORDER>), dim3((unsigned)(nh < cap ? nh : cap)), dim3(64), 0, st,
+                           rows + normal, nh, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
+                           pl->seg_lo, pl->seg_d, pl->seg_first, pl->partial);
     }
 }
 
@@ -297,8 +360,19 @@ int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* biasv, c
                        const int32_t* indices, const float* vals, int f, int ld, float* g, hipStream_t st) {
     if (pl->count[WMF_BIN_MFMA] <= 0) return 0;
     const int dbg = wmf_debug_flags;
+    // k = 16 m with biases: m blocks and a border column.  The row stream must deliver the border feature as its own
+    // dword block (lane 0), which it does unless m + 1 is a multiple of 4 (then all blocks are 16-byte pieces).
+    if (f > 16 && f % 16 == 1 && (f / 16) % 4 != 3 && !(dbg & 256)) {
+        switch (f / 16) {
+#define C_(N) case N: launch_directw_nfb<N, true>(pl, V, biasv, indptr, indices, vals, f, ld, g, dbg, st); break;
+            C_(1) C_(2) C_(4) C_(5) C_(6) C_(8)
+#undef C_
+            default: return -1;
+        }
+        return 0;
+    }
     switch ((f + 15) / 16) {
-#define C_(N) case N: launch_directw_nfb<N>(pl, V, biasv, indptr, indices, vals, f, ld, g, dbg, st); break;
+#define C_(N) case N: launch_directw_nfb<N, false>(pl, V, biasv, indptr, indices, vals, f, ld, g, dbg, st); break;
         C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9)
 #undef C_
         default: return -1;
