@@ -465,9 +465,17 @@ int wmf_launch_spmm(const float* V, const int64_t* indptr, const int32_t* indice
 // w_eff[j] = values[j] - bias[indices[j]]   (RecModel/wmf_model.py:343), one streaming pass per half step,
 // so that the row kernels never chain a dependent gather behind their index loads.
 __global__ __launch_bounds__(256) void bias_adjust_kernel(const float* __restrict__ vals, const int32_t* __restrict__ indices,
-                                                          const float* __restrict__ biasv, int64_t nnz,
+                                                          const float* __restrict__ biasv, int64_t nnz, int64_t n4,
                                                           float* __restrict__ w_eff) {
-    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * 256)
+    // n4 quads of entries go four per thread and iteration (16-byte streams, four independent bias gathers in
+    // flight); the launcher passes n4 = 0 when the caller's arrays are not 16-byte aligned (views into a larger CSR)
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
+        const int4 ix = reinterpret_cast<const int4*>(indices)[j];
+        const float4 v = reinterpret_cast<const float4*>(vals)[j];
+        const float b0 = biasv[ix.x], b1 = biasv[ix.y], b2 = biasv[ix.z], b3 = biasv[ix.w];
+        reinterpret_cast<float4*>(w_eff)[j] = make_float4(v.x - b0, v.y - b1, v.z - b2, v.w - b3);
+    }
+    for (int64_t j = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * 256)
         w_eff[j] = vals[j] - biasv[indices[j]];
 }
 
@@ -536,7 +544,9 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
         int64_t grid = (nnz + 255) / 256;
         if (grid > 8192) grid = 8192;
         WmfProfScope ps(WMF_SLOT_OTHER, st);
-        hipLaunchKernelGGL(bias_adjust_kernel, dim3((unsigned)grid), dim3(256), 0, st, vals, indices, biasv, nnz, plm->w_eff);
+        const bool aligned = ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(indices)) & 15) == 0;
+        hipLaunchKernelGGL(bias_adjust_kernel, dim3((unsigned)grid), dim3(256), 0, st, vals, indices, biasv, nnz,
+                           aligned ? (nnz >> 2) : (int64_t)0, plm->w_eff);
         vals = plm->w_eff;
         biasv = nullptr;
     }
