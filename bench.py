@@ -140,10 +140,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU over RCCL.  WMF_BENCH_BACKEND=gloo lets the multi-rank path be rehearsed on a box with fewer
+    # GPUs than ranks (ranks then share devices; timing is meaningless there, correctness of the path is not)
+    backend = os.environ.get("WMF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            torch.distributed.init_process_group(backend)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     dev = torch.device(f"cuda:{local_rank}")
