@@ -3,8 +3,8 @@
 // (wmf_directw.hip), so ONE 512-THREAD WORKGROUP takes a row and its eight waves share the 16 x 16 tiles.
 //
 // Reference arithmetic: RecModel/wmf_model.py:233-239 (per-row Gramian + np.linalg.solve); SPD whenever the
-// weights are non-negative, so a blocked Cholesky B = R^T R replaces LU; a row that is not positive definite
-// is bounced to the pivoted LU kernel below.
+// weights are non-negative, so a block LDL^T elimination replaces LU; a row that is not positive definite
+// (a non-positive pivot) is bounced to the pivoted LU kernel below.
 //
 // Tiles: (bi, bj), bi <= bj <= NFB, enumerated row by row; bj = NFB is the right hand side riding along as one
 // more block column.  Tile t belongs to wave t mod 8, accumulator slot t div 8.  Unlike wmf_direct.hip the
@@ -15,13 +15,13 @@
 // saved (440 spills with the wmf_direct.hip scheme, none here).
 //   A. entries staged 32 at a time through LDS (two register sets in flight, the next row's first chunks are
 //      requested before this row's factorisation):  tile(bi, bj) += frag[bi]^T (w frag[bj]).
-//   C. for p = 0 .. NFB-1: publish tile (p,p); wave 0 factors it and inverts the factor (wmf_tile.h);
-//      R_pj = X B_pj with the tile's own registers as the B operand; panel to LDS; B_ij -= R_pi^T R_pj.
-//   D. backward substitution with the stored inverse diagonal factors; every element of the running right hand
-//      side has exactly one writer per step, so the summation order is fixed (no atomics).
+//   C. block elimination without square roots, as in wmf_directw.hip: for p = 0 .. NFB-1 the wave that owns tile
+//      (p,p) inverts it in its registers (16 DPP Gauss-Jordan steps) and publishes X; W_pj = X B_pj with the
+//      tile's own registers as the B operand; originals and W to two LDS panels; B_ij -= B_pi^T W_pj.
+//   D. g_p = w_p - sum_{j>p} W_pj g_j, column by column; every element of the running right hand side has exactly
+//      one writer per step, so the summation order is fixed (no atomics).
 #include "wmf_common.h"
 #include "wmf_internal.h"
-#include "wmf_tile.h"
 
 template <int NFB>
 struct WideCfg {
@@ -36,12 +36,11 @@ struct WideCfg {
     static constexpr int OFF_VS = 0;
     static constexpr int OFF_W = OFF_VS + RC * LDV + 16;          // 16 spare floats: the rhs slot's unused B address stays inside
     static constexpr int OFF_P = OFF_W + RC;
-    static constexpr int OFF_D = OFF_P + RC;                       // [16][20] diagonal tile being factored
-    static constexpr int OFF_T = OFF_D + 320;                      // [NFB][16][20] inverse diagonal factors
-    static constexpr int OFF_PAN = OFF_T + NFB * 320;              // [NFB + 1][16][20] row panel
-    static constexpr int OFF_Z = OFF_PAN + (NFB + 1) * 320;        // [FP] running rhs of the backward substitution
-    static constexpr int OFF_G = OFF_Z + FP;                       // [FP] solution
-    static constexpr int OFF_FLAG = OFF_G + FP;                    // [4]
+    static constexpr int OFF_T = OFF_P + RC;                       // [NFB][16][20] inverses of the pivot tiles
+    static constexpr int OFF_PAN = OFF_T + NFB * 320;              // [NFB + 1][16][20] original tiles of block row p
+    static constexpr int OFF_PAN2 = OFF_PAN + (NFB + 1) * 320;     // [NFB + 1][16][20] W tiles of block row p
+    static constexpr int OFF_Z = OFF_PAN2 + (NFB + 1) * 320;       // [FP] running rhs of the backward pass, then the solution
+    static constexpr int OFF_FLAG = OFF_Z + FP;                    // [4]
     static constexpr int TOTAL = OFF_FLAG + 4;
 };
 
@@ -52,13 +51,13 @@ __global__ __launch_bounds__(512, 1) void solve_wide_kernel(const int32_t* __res
                                                             const int32_t* __restrict__ indices,
                                                             const float* __restrict__ vals, int f, int ld,
                                                             float* __restrict__ g, int32_t* __restrict__ fb_rows,
-                                                            int32_t* __restrict__ fb_count) {
+                                                            int32_t* __restrict__ fb_count, int dbg) {
     using C = WideCfg<NFB>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
     float* Vs = sm + C::OFF_VS; float* wsm = sm + C::OFF_W; float* psm = sm + C::OFF_P;
-    float* Dblk = sm + C::OFF_D; float* T = sm + C::OFF_T; float* Pan = sm + C::OFF_PAN;
-    float* zb = sm + C::OFF_Z; float* gs = sm + C::OFF_G; int* flag = reinterpret_cast<int*>(sm + C::OFF_FLAG);
+    float* T = sm + C::OFF_T; float* Pan = sm + C::OFF_PAN; float* Pan2 = sm + C::OFF_PAN2;
+    float* zb = sm + C::OFF_Z; int* flag = reinterpret_cast<int*>(sm + C::OFF_FLAG);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -133,7 +132,7 @@ __global__ __launch_bounds__(512, 1) void solve_wide_kernel(const int32_t* __res
             __syncthreads();
             if (c + 2 < nchunks) load_chunk(pre, wpre, lo, d, base + 2 * C::RC);
             else if (itn < count) load_chunk(pre, wpre, lon, dn, slot * C::RC);
-            const int nsteps = (nrow + 3) >> 2;
+            const int nsteps = (dbg & 2) ? 0 : (nrow + 3) >> 2;           // dbg: timing ablations (wmf_debug_set_flags)
             for (int s = 0; s < nsteps; ++s) {
                 const float wq = wsm[4 * s + q];
                 const float pb = (r == 0) ? psm[4 * s + q] : 0.f;          // rhs tile: p in column 0
@@ -157,7 +156,7 @@ __global__ __launch_bounds__(512, 1) void solve_wide_kernel(const int32_t* __res
             if (nchunks < 2) load_chunk(preB, wB, lon, dn, C::RC);
         }
 
-        // ---- C. blocked Cholesky, tiles in registers
+        // ---- C. block elimination, tiles in registers
 #pragma unroll
         for (int a = 0; a < C::NACC; ++a) {
             if (ti[a] >= 0 && ti[a] == tj[a]) {
@@ -165,22 +164,27 @@ __global__ __launch_bounds__(512, 1) void solve_wide_kernel(const int32_t* __res
                 for (int reg = 0; reg < 4; ++reg) if (r == 4 * q + reg) acc[a][reg] += 1.f;
             }
         }
+        int baddr[4];
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) baddr[kq] = (r + 16 * kq) * 4;
 #pragma unroll 1
-        for (int p = 0; p < NFB; ++p) {
+        for (int p = 0; p < ((dbg & 1) ? 0 : NFB); ++p) {
+            // (a) the wave that owns tile (p, p) inverts it in registers: a symmetric tile in accumulator layout is
+            //     the row-distributed layout of the Gauss-Jordan sweep (wmf_common.h), 16 DPP steps, no other wave waits
+            //     on a serial Cholesky.  X goes to T[p] as [row][col] for everybody's A operand.
 #pragma unroll
-            for (int a = 0; a < C::NACC; ++a) {                  // (a) publish the diagonal tile
+            for (int a = 0; a < C::NACC; ++a) {
                 if (ti[a] == p && tj[a] == p) {
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) Dblk[(4 * q + reg) * 20 + r] = acc[a][reg];
+                    f32x4 X = acc[a];
+                    bool ok = true;
+                    gj_inv_sweep(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
+                    if (!ok && lane == 0) flag[0] = 1;
+                    *reinterpret_cast<float4*>(T + p * 320 + r * 20 + 4 * q) = make_float4(X[0], X[1], X[2], X[3]);
                 }
             }
             __syncthreads();
-            if (wave == 0) {                                     // (b) factor + invert it
-                const bool ok = direct_diag(Dblk, T + p * 320, lane);
-                if (!ok && lane == 0) flag[0] = 1;
-            }
-            __syncthreads();
-            {                                                    // (c) row panel: R_pj = X B_pj, the tile itself is the B operand
+            {                                                    // (c) row panel: W_pj = X B_pj (the tile itself is the B operand);
+                                                                 //     originals to Pan1, W to Pan2, W stays in the registers
                 const float4 x4 = *reinterpret_cast<const float4*>(T + p * 320 + r * 20 + 4 * q);
 #pragma unroll
                 for (int a = 0; a < C::NACC; ++a) {
@@ -188,19 +192,20 @@ __global__ __launch_bounds__(512, 1) void solve_wide_kernel(const int32_t* __res
                         f32x4 n = f32x4{0.f, 0.f, 0.f, 0.f};
                         n = WMF_MFMA16(x4.x, acc[a][0], n); n = WMF_MFMA16(x4.y, acc[a][1], n);
                         n = WMF_MFMA16(x4.z, acc[a][2], n); n = WMF_MFMA16(x4.w, acc[a][3], n);
-                        acc[a] = n;
-                        float* dst = Pan + tj[a] * 320 + (4 * q) * 20 + r;
+                        float* d1 = Pan + tj[a] * 320 + (4 * q) * 20 + r;
+                        float* d2 = Pan2 + tj[a] * 320 + (4 * q) * 20 + r;
 #pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) dst[reg * 20] = n[reg];
+                        for (int reg = 0; reg < 4; ++reg) { d1[reg * 20] = acc[a][reg]; d2[reg * 20] = n[reg]; }
+                        acc[a] = n;
                     }
                 }
             }
             __syncthreads();
 #pragma unroll
-            for (int a = 0; a < C::NACC; ++a) {                  // (e) trailing update  B_ij -= R_pi^T R_pj,  p < i <= j <= NFB
+            for (int a = 0; a < C::NACC; ++a) {                  // (e) trailing update  B_ij -= B_pi^T W_pj,  p < i <= j <= NFB
                 if (ti[a] > p) {
                     const float* pa = Pan + ti[a] * 320 + (4 * q) * 20 + r;
-                    const float* pb = Pan + tj[a] * 320 + (4 * q) * 20 + r;
+                    const float* pb = Pan2 + tj[a] * 320 + (4 * q) * 20 + r;
                     f32x4 c = acc[a];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) c = WMF_MFMA16(-pa[e * 20], pb[e * 20], c);
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(512, 1) void solve_wide_kernel(const int32_t* __res
             }
             __syncthreads();
         }
-        // y_p = column 0 of tile (p, NFB)
+        // w_p = column 0 of tile (p, NFB) (now W_p,rhs = X_p y_p)
 #pragma unroll
         for (int a = 0; a < C::NACC; ++a) {
             if (ti[a] >= 0 && tj[a] == NFB && r == 0) {
@@ -218,20 +223,11 @@ __global__ __launch_bounds__(512, 1) void solve_wide_kernel(const int32_t* __res
             }
         }
         __syncthreads();
-        // ---- D. backward substitution  R g = y
+        // ---- D. g_p = w_p - sum_{j > p} W_pj g_j, column by column: once g_p is final every tile (i, p), i < p, takes
+        //      its product out of z_i -- one tile, hence one writer, per block i and step
 #pragma unroll 1
-        for (int p = NFB - 1; p >= 0; --p) {
-            if (wave == 0) {                                     // g_p = X_p^T z_p : lane (c' = r, q) sums c = q, q+4, ...
-                float s = 0.f;
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) { const int c = q + 4 * cc; s += T[p * 320 + c * 20 + r] * zb[16 * p + c]; }
-                s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 32);
-                if (q == 0) gs[16 * p + r] = s;
-            }
-            __syncthreads();
-            // z_i -= R_ip g_p for the tiles (i, p), i < p: one tile, hence one writer, per block i
-            const float gp = gs[16 * p + r];
+        for (int p = ((dbg & 1) ? -1 : NFB - 1); p >= 0; --p) {
+            const float gp = zb[16 * p + r];                     // final: all columns j > p have been taken out
 #pragma unroll
             for (int a = 0; a < C::NACC; ++a) {
                 if (tj[a] == p && ti[a] < p && ti[a] >= 0) {
@@ -245,6 +241,7 @@ __global__ __launch_bounds__(512, 1) void solve_wide_kernel(const int32_t* __res
             }
             __syncthreads();
         }
+        float* gs = zb;                                          // the solution is what is left in z
         const bool notpd = flag[0] != 0;
         if (notpd) {
             if (tid == 0) fb_rows[atomicAdd(fb_count, 1)] = u;   // not positive definite: the LU kernel redoes it
@@ -373,7 +370,7 @@ static void launch_wide_nfb(const int32_t* rows, int64_t count, const float* V, 
     int64_t grid = 256 * 2;                                      // one resident workgroup per CU (LDS), two rounds
     if (grid > count) grid = count;
     hipLaunchKernelGGL((solve_wide_kernel<NFB>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, rows, count, V, biasv, indptr,
-                       indices, vals, f, ld, g, fb_rows, fb_count);
+                       indices, vals, f, ld, g, fb_rows, fb_count, wmf_debug_flags);
 }
 
 int wmf_wide_supported(int f) { return f > 144 && f <= 272; }
