@@ -350,9 +350,150 @@ __global__ __launch_bounds__(64, 1) void factorize64_kernel(const double* __rest
     }
 }
 
+// ---- f <= 64, blocked: 16 x 16 blocks, fp64 MFMA for every block product -------------------------------
+// The register-resident version above is correct but 32 000 instructions long (every (column, row) pair of both
+// sweeps is unrolled): four times the instruction cache, so it runs at fetch speed (0.12 ms).  Here only the
+// 16 x 16 diagonal blocks are factored and inverted with unrolled scalar code (one copy, called per block); panels,
+// trailing updates and the block forward substitution of L^-1 are v_mfma_f64_16x16x4_f64 products on tiles in LDS.
+//   A operand: lane (r = l & 15, q = l >> 4) supplies A[r][4 kk + q];  B: B[4 kk + q][r];
+//   D: lane holds D[q + 4 v][r] in element v (the f64 form's row order differs from the f32 one).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+#define WMF_MFMA16_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+constexpr int FZ_LD = 66;                              // row stride (doubles) of the 64 x 64 LDS images
+
+// D (+)= A . B^T for 16 x 16 tiles in LDS (row-major, stride FZ_LD): D[m][n] = sum_k A[m][k] B[n][k]
+__device__ __forceinline__ f64x4 fz_mul_abt(const double* __restrict__ A, const double* __restrict__ B, f64x4 c, int r, int q,
+                                            double sign) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) c = WMF_MFMA16_F64(sign * A[r * FZ_LD + 4 * kk + q], B[r * FZ_LD + 4 * kk + q], c);
+    return c;
+}
+// D (+)= A . B : D[m][n] = sum_k A[m][k] B[k][n]
+__device__ __forceinline__ f64x4 fz_mul_ab(const double* __restrict__ A, const double* __restrict__ B, f64x4 c, int r, int q,
+                                           double sign) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) c = WMF_MFMA16_F64(sign * A[r * FZ_LD + 4 * kk + q], B[(4 * kk + q) * FZ_LD + r], c);
+    return c;
+}
+__device__ __forceinline__ f64x4 fz_load(const double* __restrict__ T, int r, int q) {
+    return f64x4{T[q * FZ_LD + r], T[(q + 4) * FZ_LD + r], T[(q + 8) * FZ_LD + r], T[(q + 12) * FZ_LD + r]};
+}
+__device__ __forceinline__ void fz_store(double* __restrict__ T, const f64x4& c, int r, int q) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) T[(q + 4 * v) * FZ_LD + r] = c[v];
+}
+// Cholesky of the 16 x 16 block D (lower part read) -> L into Lt (upper part zeroed), L^-1 into Xt.  Lane i < 16
+// owns row i of D and L; lane j builds column j of the inverse.  One copy of the unrolled code for all blocks.
+__device__ __noinline__ bool fz_diag(const double* __restrict__ D, double* __restrict__ Lt, double* __restrict__ Xt, int lane) {
+    const int row = lane & 15;
+    double a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = D[row * FZ_LD + j];
+    bool ok = true;
+    double rinv[16];                                               // 1 / L[K][K]: the substitution below multiplies by it
+#pragma unroll
+    for (int K = 0; K < 16; ++K) {
+        const double dk = rl_f64(a[K], K);
+        if (!(dk > 0.0)) ok = false;
+        // 1 / sqrt(dk): hardware estimate + two Newton steps (full double precision; the library sqrt and divide are
+        // each a long dependent sequence, and this chain is serial over the 16 columns)
+        double y = __builtin_amdgcn_rsq(dk);
+        y = y * (1.5 - 0.5 * dk * y * y);
+        y = y * (1.5 - 0.5 * dk * y * y);
+        rinv[K] = y;
+        a[K] *= y;                                                  // lane K: sqrt(dk); lanes > K: L[i][K]
+#pragma unroll
+        for (int j = K + 1; j < 16; ++j) a[j] -= a[K] * rl_f64(a[K], j);
+    }
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        double sacc = (i == row) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) sacc -= rl_f64(a[k], i) * x[k];
+        x[i] = sacc * rinv[i];
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            Lt[row * FZ_LD + j] = (j <= row) ? a[j] : 0.0;        // row `row` of L
+            Xt[j * FZ_LD + row] = x[j];                            // column `row` of L^-1 (zero above the diagonal)
+        }
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(64, 1) void factorize64m_kernel(const double* __restrict__ G, int f, int ld, double lambda,
+                                                             float* __restrict__ Wwhite, float* __restrict__ Wunwhite,
+                                                             int32_t* __restrict__ info) {
+    __shared__ __attribute__((aligned(16))) double Gs[64 * FZ_LD];   // working matrix, becomes L (block lower triangle)
+    __shared__ __attribute__((aligned(16))) double Xs[64 * FZ_LD];   // L^-1
+    __shared__ __attribute__((aligned(16))) double Ts[16 * FZ_LD];   // one scratch tile
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    const int nb = (f + 15) >> 4;
+#pragma unroll 16
+    for (int i = 0; i < 64; ++i) {                                   // row i, column `lane`: 16 independent loads in flight
+        const int j = lane;
+        double v = (i == j) ? 1.0 : 0.0;                             // identity padding for rows / columns >= f
+        const double gv = G[min(i, f - 1) * f + min(j, f - 1)];
+        if (i < f && j < f) v = gv + (i == j ? lambda : 0.0);
+        Gs[i * FZ_LD + j] = v;
+        Xs[i * FZ_LD + j] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bool ok = true;
+    auto tile = [&](double* M, int bi, int bj) { return M + (16 * bi) * FZ_LD + 16 * bj; };
+    auto sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    for (int p = 0; p < nb; ++p) {
+        ok = fz_diag(tile(Gs, p, p), tile(Gs, p, p), tile(Xs, p, p), lane) && ok;     // in place: row i is read before it is written
+        sync();
+        for (int i = p + 1; i < nb; ++i) {                           // L_ip = G_ip . (L_pp^-1)^T
+            const f64x4 c = fz_mul_abt(tile(Gs, i, p), tile(Xs, p, p), f64x4{0.0, 0.0, 0.0, 0.0}, r, q, 1.0);
+            sync();
+            fz_store(tile(Gs, i, p), c, r, q);
+            sync();
+        }
+        for (int i = p + 1; i < nb; ++i)                             // G_ij -= L_ip . L_jp^T,  p < j <= i
+            for (int j = p + 1; j <= i; ++j) {
+                const f64x4 c = fz_mul_abt(tile(Gs, i, p), tile(Gs, j, p), fz_load(tile(Gs, i, j), r, q), r, q, -1.0);
+                fz_store(tile(Gs, i, j), c, r, q);
+            }
+        sync();
+    }
+    // block forward substitution: X_ip = -X_ii . sum_{k = p .. i-1} L_ik X_kp
+    for (int p = 0; p < nb; ++p)
+        for (int i = p + 1; i < nb; ++i) {
+            f64x4 sacc = f64x4{0.0, 0.0, 0.0, 0.0};
+            for (int k = p; k < i; ++k) sacc = fz_mul_ab(tile(Gs, i, k), tile(Xs, k, p), sacc, r, q, 1.0);
+            fz_store(Ts, sacc, r, q);
+            sync();
+            const f64x4 c = fz_mul_ab(tile(Xs, i, i), Ts, f64x4{0.0, 0.0, 0.0, 0.0}, r, q, -1.0);
+            fz_store(tile(Xs, i, p), c, r, q);
+            sync();
+        }
+    if (lane == 0) *info = ok ? 0 : 1;
+    // Wunwhite[i][j] = X[i][j],  Wwhite[j][i] = X[i][j]; padding columns [f, ld) zero
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+        if (i >= f) break;
+        for (int j = lane; j < ld; j += 64) {                        // ld <= 64 here: one pass
+            float wu = 0.f, ww = 0.f;
+            if (j < f && ok) { wu = (float)Xs[i * FZ_LD + j]; ww = (float)Xs[j * FZ_LD + i]; }
+            Wunwhite[i * ld + j] = wu;
+            Wwhite[i * ld + j] = ww;
+        }
+    }
+}
+
 int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, float* Wwhite, float* Wunwhite,
                          int32_t* info, double* gA, hipStream_t st) {
-    if (f <= 64) {                                   // register-resident single-wave version
+    if (f <= 64 && !(wmf_debug_flags & 512)) {       // blocked single-wave version (fp64 MFMA)
+        WmfProfScope ps(WMF_SLOT_FACTORIZE, st);
+        hipLaunchKernelGGL(factorize64m_kernel, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
+        return 0;
+    }
+    if (f <= 64) {                                   // register-resident single-wave version (debug flag 512: A/B timing)
         WmfProfScope ps(WMF_SLOT_FACTORIZE, st);
         if (f <= 16) hipLaunchKernelGGL(factorize64_kernel<16>, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
         else if (f <= 32) hipLaunchKernelGGL(factorize64_kernel<32>, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
