@@ -93,7 +93,7 @@ const char* wmf_last_error(void) { return g_err; }
 int wmf_version(void) { return 100; }
 int wmf_ld_for(int f) { return (f + 3) & ~3; }
 
-// ---- workspace layout of gram/factorize: [partials fp32][slices fp64 32 x f x f][A fp64 f x (f|1)] ----
+// ---- workspace layout of gram/factorize: [partials fp32][slices fp64 32 x f x f][two fp64 images fp x (fp + 2), fp = 16 ceil(f / 16)] ----
 static int64_t gram_partial_bytes(int f) {
     const int64_t nfb = (f + 15) / 16, nt = nfb * (nfb + 1) / 2;
     return (int64_t)wmf_gram_max_waves(f) * nt * 256 * (int64_t)sizeof(float);
@@ -102,7 +102,8 @@ static int64_t gram_slices_off(int f) { return (gram_partial_bytes(f) + 255) & ~
 static int64_t gram_a_off(int f) { return (gram_slices_off(f) + (int64_t)32 * f * f * 8 + 255) & ~(int64_t)255; }
 int64_t wmf_gram_workspace_bytes(int f) {
     if (f < 1 || f > WMF_MAX_F) return 0;
-    return gram_a_off(f) + (int64_t)f * (f | 1) * (int64_t)sizeof(double) + 256;
+    const int64_t fp = 16 * ((f + 15) / 16);
+    return gram_a_off(f) + 2 * fp * (fp + 2) * (int64_t)sizeof(double) + 256;
 }
 
 int wmf_gram(const float* Y, int64_t m, int f, int ld, int bias, double* G_sum, void* workspace, void* stream) {

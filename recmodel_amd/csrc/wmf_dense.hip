@@ -361,34 +361,33 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define WMF_MFMA16_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 constexpr int FZ_LD = 66;                              // row stride (doubles) of the 64 x 64 LDS images
 
-// D (+)= A . B^T for 16 x 16 tiles in LDS (row-major, stride FZ_LD): D[m][n] = sum_k A[m][k] B[n][k]
-__device__ __forceinline__ f64x4 fz_mul_abt(const double* __restrict__ A, const double* __restrict__ B, f64x4 c, int r, int q,
-                                            double sign) {
+// Tiles are 16 x 16 windows of row-major images with row strides la / lb / lt (doubles).
+// D (+)= A . B^T : D[m][n] = sum_k A[m][k] B[n][k]
+__device__ __forceinline__ f64x4 fz_mul_abt(const double* A, int la, const double* B, int lb, f64x4 c, int r, int q, double sign) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) c = WMF_MFMA16_F64(sign * A[r * FZ_LD + 4 * kk + q], B[r * FZ_LD + 4 * kk + q], c);
+    for (int kk = 0; kk < 4; ++kk) c = WMF_MFMA16_F64(sign * A[r * la + 4 * kk + q], B[r * lb + 4 * kk + q], c);
     return c;
 }
 // D (+)= A . B : D[m][n] = sum_k A[m][k] B[k][n]
-__device__ __forceinline__ f64x4 fz_mul_ab(const double* __restrict__ A, const double* __restrict__ B, f64x4 c, int r, int q,
-                                           double sign) {
+__device__ __forceinline__ f64x4 fz_mul_ab(const double* A, int la, const double* B, int lb, f64x4 c, int r, int q, double sign) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) c = WMF_MFMA16_F64(sign * A[r * FZ_LD + 4 * kk + q], B[(4 * kk + q) * FZ_LD + r], c);
+    for (int kk = 0; kk < 4; ++kk) c = WMF_MFMA16_F64(sign * A[r * la + 4 * kk + q], B[(4 * kk + q) * lb + r], c);
     return c;
 }
-__device__ __forceinline__ f64x4 fz_load(const double* __restrict__ T, int r, int q) {
-    return f64x4{T[q * FZ_LD + r], T[(q + 4) * FZ_LD + r], T[(q + 8) * FZ_LD + r], T[(q + 12) * FZ_LD + r]};
+__device__ __forceinline__ f64x4 fz_load(const double* T, int lt, int r, int q) {
+    return f64x4{T[q * lt + r], T[(q + 4) * lt + r], T[(q + 8) * lt + r], T[(q + 12) * lt + r]};
 }
-__device__ __forceinline__ void fz_store(double* __restrict__ T, const f64x4& c, int r, int q) {
+__device__ __forceinline__ void fz_store(double* T, int lt, const f64x4& c, int r, int q) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) T[(q + 4 * v) * FZ_LD + r] = c[v];
+    for (int v = 0; v < 4; ++v) T[(q + 4 * v) * lt + r] = c[v];
 }
 // Cholesky of the 16 x 16 block D (lower part read) -> L into Lt (upper part zeroed), L^-1 into Xt.  Lane i < 16
 // owns row i of D and L; lane j builds column j of the inverse.  One copy of the unrolled code for all blocks.
-__device__ __noinline__ bool fz_diag(const double* __restrict__ D, double* __restrict__ Lt, double* __restrict__ Xt, int lane) {
+__device__ __noinline__ bool fz_diag(const double* D, double* Lt, double* Xt, int lt, int lane) {
     const int row = lane & 15;
     double a[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = D[row * FZ_LD + j];
+    for (int j = 0; j < 16; ++j) a[j] = D[row * lt + j];
     bool ok = true;
     double rinv[16];                                               // 1 / L[K][K]: the substitution below multiplies by it
 #pragma unroll
@@ -416,8 +415,8 @@ __device__ __noinline__ bool fz_diag(const double* __restrict__ D, double* __res
     if (lane < 16) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            Lt[row * FZ_LD + j] = (j <= row) ? a[j] : 0.0;        // row `row` of L
-            Xt[j * FZ_LD + row] = x[j];                            // column `row` of L^-1 (zero above the diagonal)
+            Lt[row * lt + j] = (j <= row) ? a[j] : 0.0;           // row `row` of L
+            Xt[j * lt + row] = x[j];                               // column `row` of L^-1 (zero above the diagonal)
         }
     }
     return ok;
@@ -446,18 +445,18 @@ __global__ __launch_bounds__(64, 1) void factorize64m_kernel(const double* __res
     auto tile = [&](double* M, int bi, int bj) { return M + (16 * bi) * FZ_LD + 16 * bj; };
     auto sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     for (int p = 0; p < nb; ++p) {
-        ok = fz_diag(tile(Gs, p, p), tile(Gs, p, p), tile(Xs, p, p), lane) && ok;     // in place: row i is read before it is written
+        ok = fz_diag(tile(Gs, p, p), tile(Gs, p, p), tile(Xs, p, p), FZ_LD, lane) && ok;     // in place: row i is read before it is written
         sync();
         for (int i = p + 1; i < nb; ++i) {                           // L_ip = G_ip . (L_pp^-1)^T
-            const f64x4 c = fz_mul_abt(tile(Gs, i, p), tile(Xs, p, p), f64x4{0.0, 0.0, 0.0, 0.0}, r, q, 1.0);
+            const f64x4 c = fz_mul_abt(tile(Gs, i, p), FZ_LD, tile(Xs, p, p), FZ_LD, f64x4{0.0, 0.0, 0.0, 0.0}, r, q, 1.0);
             sync();
-            fz_store(tile(Gs, i, p), c, r, q);
+            fz_store(tile(Gs, i, p), FZ_LD, c, r, q);
             sync();
         }
         for (int i = p + 1; i < nb; ++i)                             // G_ij -= L_ip . L_jp^T,  p < j <= i
             for (int j = p + 1; j <= i; ++j) {
-                const f64x4 c = fz_mul_abt(tile(Gs, i, p), tile(Gs, j, p), fz_load(tile(Gs, i, j), r, q), r, q, -1.0);
-                fz_store(tile(Gs, i, j), c, r, q);
+                const f64x4 c = fz_mul_abt(tile(Gs, i, p), FZ_LD, tile(Gs, j, p), FZ_LD, fz_load(tile(Gs, i, j), FZ_LD, r, q), r, q, -1.0);
+                fz_store(tile(Gs, i, j), FZ_LD, c, r, q);
             }
         sync();
     }
@@ -465,11 +464,11 @@ __global__ __launch_bounds__(64, 1) void factorize64m_kernel(const double* __res
     for (int p = 0; p < nb; ++p)
         for (int i = p + 1; i < nb; ++i) {
             f64x4 sacc = f64x4{0.0, 0.0, 0.0, 0.0};
-            for (int k = p; k < i; ++k) sacc = fz_mul_ab(tile(Gs, i, k), tile(Xs, k, p), sacc, r, q, 1.0);
-            fz_store(Ts, sacc, r, q);
+            for (int k = p; k < i; ++k) sacc = fz_mul_ab(tile(Gs, i, k), FZ_LD, tile(Xs, k, p), FZ_LD, sacc, r, q, 1.0);
+            fz_store(Ts, FZ_LD, sacc, r, q);
             sync();
-            const f64x4 c = fz_mul_ab(tile(Xs, i, i), Ts, f64x4{0.0, 0.0, 0.0, 0.0}, r, q, -1.0);
-            fz_store(tile(Xs, i, p), c, r, q);
+            const f64x4 c = fz_mul_ab(tile(Xs, i, i), FZ_LD, Ts, FZ_LD, f64x4{0.0, 0.0, 0.0, 0.0}, r, q, -1.0);
+            fz_store(tile(Xs, i, p), FZ_LD, c, r, q);
             sync();
         }
     if (lane == 0) *info = ok ? 0 : 1;
@@ -486,6 +485,75 @@ __global__ __launch_bounds__(64, 1) void factorize64m_kernel(const double* __res
     }
 }
 
+// ---- 64 < f <= 272, blocked: the same algorithm with the two images in a global workspace (L2 resident) and the
+// independent tile products of each step dealt to the eight waves of one workgroup.  The columns of L^-1 are
+// independent of each other, so each wave substitutes its own columns without further barriers.
+__global__ __launch_bounds__(512, 1) void factorize_blocked_kernel(const double* __restrict__ G, int f, int ld, double lambda,
+                                                                   float* __restrict__ Wwhite, float* __restrict__ Wunwhite,
+                                                                   int32_t* __restrict__ info, double* __restrict__ work) {
+    __shared__ __attribute__((aligned(16))) double Ts[8][16 * 18];   // one scratch tile per wave
+    __shared__ int bad;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = (f + 15) >> 4, fp = 16 * nb, LD = fp + 2;
+    double* A = work;                                                // fp x LD: working matrix, becomes L
+    double* X = work + (size_t)fp * LD;                              // fp x LD: L^-1
+    if (tid == 0) bad = 0;
+    for (int e = tid; e < fp * fp; e += 512) {
+        const int i = e / fp, j = e % fp;
+        double v = (i == j) ? 1.0 : 0.0;                             // identity padding for rows / columns >= f
+        if (i < f && j < f) v = G[i * f + j] + (i == j ? lambda : 0.0);
+        A[i * LD + j] = v;
+        X[i * LD + j] = 0.0;
+    }
+    __syncthreads();
+    auto tile = [&](double* M, int bi, int bj) { return M + (size_t)(16 * bi) * LD + 16 * bj; };
+    for (int p = 0; p < nb; ++p) {
+        if (wave == 0) {
+            const bool ok = fz_diag(tile(A, p, p), tile(A, p, p), tile(X, p, p), LD, lane);
+            if (!ok && lane == 0) bad = 1;
+        }
+        __syncthreads();
+        for (int i = p + 1 + wave; i < nb; i += 8) {                 // L_ip = A_ip . (L_pp^-1)^T, in place
+            const f64x4 c = fz_mul_abt(tile(A, i, p), LD, tile(X, p, p), LD, f64x4{0.0, 0.0, 0.0, 0.0}, r, q, 1.0);
+            fz_store(tile(A, i, p), LD, c, r, q);
+        }
+        __syncthreads();
+        int t = 0;
+        for (int i = p + 1; i < nb; ++i)                             // A_ij -= L_ip . L_jp^T,  p < j <= i
+            for (int j = p + 1; j <= i; ++j, ++t) {
+                if ((t & 7) != wave) continue;
+                const f64x4 c = fz_mul_abt(tile(A, i, p), LD, tile(A, j, p), LD, fz_load(tile(A, i, j), LD, r, q), r, q, -1.0);
+                fz_store(tile(A, i, j), LD, c, r, q);
+            }
+        __syncthreads();
+    }
+    // X_ip = -X_ii . sum_{k = p .. i-1} L_ik X_kp, column p by wave p mod 8
+    double* ts = Ts[wave];
+    for (int p = wave; p < nb; p += 8)
+        for (int i = p + 1; i < nb; ++i) {
+            f64x4 sacc = f64x4{0.0, 0.0, 0.0, 0.0};
+            for (int k = p; k < i; ++k) sacc = fz_mul_ab(tile(A, i, k), LD, tile(X, k, p), LD, sacc, r, q, 1.0);
+            fz_store(ts, 18, sacc, r, q);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const f64x4 c = fz_mul_ab(tile(X, i, i), LD, ts, 18, f64x4{0.0, 0.0, 0.0, 0.0}, r, q, -1.0);
+            fz_store(tile(X, i, p), LD, c, r, q);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    __syncthreads();
+    const bool ok = bad == 0;
+    if (tid == 0) *info = ok ? 0 : 1;
+    for (int e = tid; e < f * ld; e += 512) {
+        const int i = e / ld, j = e % ld;
+        float wu = 0.f, ww = 0.f;
+        if (j < f && ok) { wu = (float)X[i * LD + j]; ww = (float)X[j * LD + i]; }
+        Wunwhite[e] = wu;
+        Wwhite[e] = ww;
+    }
+}
+
 int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, float* Wwhite, float* Wunwhite,
                          int32_t* info, double* gA, hipStream_t st) {
     if (f <= 64 && !(wmf_debug_flags & 512)) {       // blocked single-wave version (fp64 MFMA)
@@ -499,6 +567,11 @@ int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, floa
         else if (f <= 32) hipLaunchKernelGGL(factorize64_kernel<32>, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
         else if (f <= 48) hipLaunchKernelGGL(factorize64_kernel<48>, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
         else hipLaunchKernelGGL(factorize64_kernel<64>, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
+        return 0;
+    }
+    if (!(wmf_debug_flags & 512)) {                  // blocked workgroup version (fp64 MFMA); flag 512: the older kernel below
+        WmfProfScope ps(WMF_SLOT_FACTORIZE, st);
+        hipLaunchKernelGGL(factorize_blocked_kernel, dim3(1), dim3(512), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info, gA);
         return 0;
     }
     const int lda = f | 1;
