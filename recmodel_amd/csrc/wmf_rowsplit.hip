@@ -1,0 +1,320 @@
+// Rows with more than 32 stored entries when 144 < f <= 256 (k = 256 without biases, and every width between):
+// the f x f whitened system  (I + V_u^T D V_u) g = V_u^T p  is too big for one wave's accumulators
+// (wmf_directw.hip), so FOUR waves share it BY BLOCK ROWS.  Reference arithmetic: RecModel/wmf_model.py:233-239.
+//
+// Tile (bi, bj), bi <= bj < NFB <= 16, of the upper triangle lives in the accumulators of the wave that owns block
+// row bi.  Wave w owns rows {w, 7 - w, 8 + w, 15 - w}: 34 tiles each for NFB = 16 (136 accumulator registers), and
+// because w is a compile-time constant of the code a wave runs (four specialised copies of the row code, selected
+// once per workgroup), every accumulator index AND every LDS offset is an immediate:
+//   A. entries are staged 16 at a time through LDS; per k-step a wave reads the NFB fragments once (they are the
+//      B operands of all its tiles and, for its own four rows, the A operands) and issues its 34 MFMAs back to
+//      back:  tile(bi, bj) += frag[bi]^T (w frag[bj]);  the right-hand side y[bi] += p frag[bi] stays on the VALU.
+//   C. block LDL^T as in wmf_directw.hip: the owner of row p inverts tile (p, p) in its registers (16 DPP
+//      Gauss-Jordan steps), forms W_pj = X B_pj for its whole row without any exchange, publishes the original row
+//      and the W row to two LDS panels, and after a barrier every wave updates its own rows, B_ij -= B_pi^T W_pj
+//      and y_i -= B_pi^T w_p (w_p = X y_p); a second barrier frees the panels.  Two workgroups share a CU, so one
+//      computes while the other waits for its pivot.
+//   D. g_p = w_p - sum_{j>p} W_pj g_j: the owner of row p has every W_pj in registers; rows are finished from the
+//      last to the first, one barrier each.
+// A non-positive pivot bounces the row to the pivoted LU kernel (wmf_wide.hip).  Compared with the run-time-indexed
+// kernel in wmf_wide.hip (still used for f > 256): no LDS operand reads inside the MFMA stream beyond the shared
+// fragments, no register or scalar spills, two barriers per pivot instead of three.
+#include "wmf_common.h"
+#include "wmf_internal.h"
+
+#include <utility>
+
+template <int NFB>
+struct RsCfg {
+    static constexpr int NW = 4, NTHR = 256;
+    static constexpr int FP = 16 * NFB;
+    static constexpr int LDV = (FP % 32 == 16) ? FP : FP + 16;   // = 16 (mod 32): the two k rows of a half wave hit disjoint banks
+    static constexpr int RC = 16;                                 // staged entries per chunk
+    static constexpr int PF = (RC * (FP / 4) + NTHR - 1) / NTHR;  // 16-byte pieces prefetched per thread and chunk
+    // LDS carve (floats)
+    static constexpr int OFF_VS = 0;                              // [RC][LDV] staged factor rows
+    static constexpr int OFF_W = OFF_VS + RC * LDV;               // [RC] weights
+    static constexpr int OFF_P = OFF_W + RC;                      // [RC] w + 1 (0 past the end of the row)
+    static constexpr int OFF_PAN = OFF_P + RC;                    // [2][NFB][16][20]: {originals, W} of the pivot row, by block column
+    static constexpr int OFF_WV = OFF_PAN + 2 * NFB * 320;        // [16] w_p of the pivot row (+ spare)
+    static constexpr int OFF_G = OFF_WV + 32;                     // [FP] solution
+    static constexpr int OFF_FLAG = OFF_G + FP;                   // [4]
+    static constexpr int TOTAL = OFF_FLAG + 4;
+};
+
+// block rows of wave W, in increasing order; a row >= NFB does not exist
+template <int W> __device__ __host__ constexpr int rs_row(int s) { return s == 0 ? W : (s == 1 ? 7 - W : (s == 2 ? 8 + W : 15 - W)); }
+// first accumulator of row slot s: rows hold NFB - row tiles each (columns row .. NFB - 1)
+template <int NFB, int W> __device__ __host__ constexpr int rs_base(int s) {
+    int b = 0;
+    for (int t = 0; t < s; ++t) b += rs_row<W>(t) < NFB ? NFB - rs_row<W>(t) : 0;
+    return b;
+}
+template <int NFB, int W> __device__ __host__ constexpr int rs_ntiles() { return rs_base<NFB, W>(4); }
+
+template <int NFB, int W>
+__device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* __restrict__ rows, int64_t count,
+                                        const float* __restrict__ V, const float* __restrict__ biasv,
+                                        const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                        const float* __restrict__ vals, int f, int ld, float* __restrict__ g,
+                                        int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int dbg) {
+    using C = RsCfg<NFB>;
+    constexpr int NT = rs_ntiles<NFB, W>();
+    float* Vs = sm + C::OFF_VS; float* wsm = sm + C::OFF_W; float* psm = sm + C::OFF_P;
+    float* Pan = sm + C::OFF_PAN; float* Wv = sm + C::OFF_WV; float* gs = sm + C::OFF_G;
+    int* flag = reinterpret_cast<int*>(sm + C::OFF_FLAG);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int nch = ld >> 2;
+    int baddr[4];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) baddr[kq] = (r + 16 * kq) * 4;
+
+    // per-thread (row-in-chunk, piece) of each prefetched 16-byte piece; fixed across chunks
+    int pj[C::PF], pc[C::PF];
+#pragma unroll
+    for (int i = 0; i < C::PF; ++i) { const int e = tid + C::NTHR * i; pj[i] = e / nch; pc[i] = e % nch; }
+    float4 pre[C::PF];                                           // ONE staged chunk in flight (registers are what limits two
+    float wpre = 0.f;                                            // workgroups per CU): requested while the previous one is consumed
+    auto load_chunk = [&](int64_t lo_, int d_, int base) {
+        const int nrow = min(C::RC, d_ - base);                  // may be <= 0: everything masked
+#pragma unroll
+        for (int i = 0; i < C::PF; ++i) {                        // unconditional loads, masked by multiplication
+            const float on = pj[i] < nrow ? 1.f : 0.f;
+            const int idx = indices[pj[i] < nrow ? lo_ + base + pj[i] : 0];
+            const float4 v = reinterpret_cast<const float4*>(V + (int64_t)idx * ld)[pc[i]];
+            pre[i] = make_float4(v.x * on, v.y * on, v.z * on, v.w * on);
+        }
+        {
+            const bool on = tid < nrow;
+            const int64_t e = on ? lo_ + base + tid : 0;
+            float wv = vals[e];
+            if (biasv) wv -= biasv[indices[e]];
+            wpre = on ? wv : 0.f;
+        }
+    };
+    for (int e = tid; e < C::RC * C::LDV; e += C::NTHR) Vs[e] = 0.f;       // pad columns [ld, LDV) stay zero for good
+
+    int64_t it = blockIdx.x;
+    int u = 0, d = 0;
+    int64_t lo = 0;
+    if (it < count) {
+        u = rows[it]; lo = indptr[u]; d = (int)(indptr[u + 1] - lo);
+        load_chunk(lo, d, 0);
+    }
+    for (; it < count; it += gridDim.x) {
+        const int nchunks = (d + C::RC - 1) / C::RC;
+        const int64_t itn = it + gridDim.x;
+        int un = 0, dn = 0;
+        int64_t lon = 0;
+        if (itn < count) { un = rows[itn]; lon = indptr[un]; dn = (int)(indptr[un + 1] - lon); }
+
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float yacc[4] = {0.f, 0.f, 0.f, 0.f};                    // this lane's q share of y[16 row + r], per row slot
+        if (tid == 0) flag[0] = 0;
+
+        // ---- A
+        for (int c = 0; c < nchunks; ++c) {
+            const int base = c * C::RC;
+            const int nrow = min(C::RC, d - base);
+            __syncthreads();                                     // everyone finished reading the previous chunk
+#pragma unroll
+            for (int i = 0; i < C::PF; ++i)
+                if (pj[i] < C::RC) *reinterpret_cast<float4*>(&Vs[pj[i] * C::LDV + 4 * pc[i]]) = pre[i];   // zeros beyond nrow
+            if (tid < C::RC) { wsm[tid] = wpre; psm[tid] = (tid < nrow) ? wpre + 1.f : 0.f; }
+            __syncthreads();
+            if (c + 1 < nchunks) load_chunk(lo, d, base + C::RC);
+            else if (itn < count) load_chunk(lon, dn, 0);        // the next row's first chunk flies during the elimination
+            const int nsteps = (dbg & 2) ? 0 : (nrow + 3) >> 2;  // dbg: timing ablations (wmf_debug_set_flags)
+            for (int ks = 0; ks < nsteps; ++ks) {
+                const float wq = wsm[4 * ks + q], pq = psm[4 * ks + q];
+                const float* vrow = Vs + (4 * ks + q) * C::LDV + r;
+                float fw[NFB];                                   // w * fragment: the B operands of every tile of column bj
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) fw[fb] = vrow[16 * fb] * wq;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int bi = rs_row<W>(s);
+                    if (bi < NFB) {
+                        const float fa = vrow[16 * bi];          // this row's fragment again (A operand): an LDS read is cheaper than a register
+                        yacc[s] += fa * pq;
+#pragma unroll
+                        for (int bj = bi; bj < NFB; ++bj) {
+                            const int t = rs_base<NFB, W>(s) + bj - bi;
+                            acc[t] = WMF_MFMA16(fa, fw[bj], acc[t]);
+                        }
+                    }
+                }
+            }
+        }
+        if (nchunks == 0 && itn < count) load_chunk(lon, dn, 0);
+
+        // ---- C: block elimination
+        bool ok = true;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (rs_row<W>(s) < NFB) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) if (r == 4 * q + reg) acc[rs_base<NFB, W>(s)][reg] += 1.f;
+            }
+        }
+        // pivot-row work of row slot S (compile time); the caller checks p == rs_row<W>(S)
+        auto pivot_row = [&](auto slot_c, int p, float* P1, float* P2, float* wv_out) {
+            constexpr int S = decltype(slot_c)::value;
+            constexpr int bi = rs_row<W>(S);
+            constexpr int b0 = rs_base<NFB, W>(S);
+            if constexpr (bi < NFB) {
+                f32x4 X = acc[b0];
+                gj_inv_sweep(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
+                float yp = yacc[S];
+                yp += __shfl_xor(yp, 16);
+                yp += __shfl_xor(yp, 32);
+                float wv0 = X[0] * yp, wv1 = X[1] * yp, wv2 = X[2] * yp, wv3 = X[3] * yp;
+                wmf_row16_sum4(wv0, wv1, wv2, wv3);              // w_p[4q + reg] on the whole 16-lane row
+                if (r == 0) {
+                    *reinterpret_cast<float4*>(wv_out + 4 * q) = make_float4(wv0, wv1, wv2, wv3);
+                    *reinterpret_cast<float4*>(gs + 16 * bi + 4 * q) = make_float4(wv0, wv1, wv2, wv3);   // start of the backward pass
+                }
+#pragma unroll
+                for (int bj = bi + 1; bj < NFB; ++bj) {
+                    const int t = b0 + bj - bi;
+                    f32x4 n = f32x4{0.f, 0.f, 0.f, 0.f};
+                    n = WMF_MFMA16(X[0], acc[t][0], n); n = WMF_MFMA16(X[1], acc[t][1], n);
+                    n = WMF_MFMA16(X[2], acc[t][2], n); n = WMF_MFMA16(X[3], acc[t][3], n);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        P1[bj * 320 + (4 * q + reg) * 20 + r] = acc[t][reg];
+                        P2[bj * 320 + (4 * q + reg) * 20 + r] = n[reg];
+                    }
+                    acc[t] = n;                                  // W_pj stays in registers for the backward pass
+                }
+            }
+            (void)p;
+        };
+        if (!(dbg & 1)) {
+#pragma unroll 1
+            for (int p = 0; p < NFB; ++p) {
+                float* P1 = Pan;                                 // originals of block row p
+                float* P2 = Pan + NFB * 320;                     // W tiles of block row p
+                float* wvp = Wv;
+                if (p == rs_row<W>(0)) pivot_row(std::integral_constant<int, 0>{}, p, P1, P2, wvp);
+                else if (p == rs_row<W>(1)) pivot_row(std::integral_constant<int, 1>{}, p, P1, P2, wvp);
+                else if (p == rs_row<W>(2)) pivot_row(std::integral_constant<int, 2>{}, p, P1, P2, wvp);
+                else if (p == rs_row<W>(3)) pivot_row(std::integral_constant<int, 3>{}, p, P1, P2, wvp);
+                __syncthreads();                                 // panels of row p published
+                const float4 w4 = *reinterpret_cast<const float4*>(wvp + 4 * q);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int bi = rs_row<W>(s);
+                    if (bi < NFB && bi > p) {                    // compile-time row, run-time pivot: a uniform branch per row
+                        float a[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[e] = -P1[bi * 320 + (4 * q + e) * 20 + r];
+                        yacc[s] += a[0] * w4.x + a[1] * w4.y + a[2] * w4.z + a[3] * w4.w;
+#pragma unroll
+                        for (int bj = bi; bj < NFB; ++bj) {
+                            const int t = rs_base<NFB, W>(s) + bj - bi;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[t] = WMF_MFMA16(a[e], P2[bj * 320 + (4 * q + e) * 20 + r], acc[t]);
+                        }
+                    }
+                }
+                __syncthreads();                                 // everyone has read the panels: the next pivot may overwrite them
+            }
+            if (!ok && lane == 0) flag[0] = 1;
+            __syncthreads();
+            // ---- D: rows from the last to the first; gs[16 p ..] holds w_p until row p is finished
+#pragma unroll 1
+            for (int p = NFB - 1; p >= 0; --p) {
+                auto back_row = [&](auto slot_c) {
+                    constexpr int S = decltype(slot_c)::value;
+                    constexpr int bi = rs_row<W>(S);
+                    constexpr int b0 = rs_base<NFB, W>(S);
+                    if constexpr (bi < NFB && bi + 1 < NFB) {
+                        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int bj = bi + 1; bj < NFB; ++bj) {
+                            const float gj = gs[16 * bj + r];    // g_j[r], final
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) s4[reg] += acc[b0 + bj - bi][reg] * gj;
+                        }
+                        wmf_row16_sum4(s4[0], s4[1], s4[2], s4[3]);
+                        if (r == 0) {
+                            float* z = gs + 16 * bi + 4 * q;
+                            z[0] -= s4[0]; z[1] -= s4[1]; z[2] -= s4[2]; z[3] -= s4[3];
+                        }
+                    }
+                };
+                if (p == rs_row<W>(0)) back_row(std::integral_constant<int, 0>{});
+                else if (p == rs_row<W>(1)) back_row(std::integral_constant<int, 1>{});
+                else if (p == rs_row<W>(2)) back_row(std::integral_constant<int, 2>{});
+                else if (p == rs_row<W>(3)) back_row(std::integral_constant<int, 3>{});
+                __syncthreads();
+            }
+        } else {
+            __syncthreads();
+        }
+        const bool notpd = flag[0] != 0;
+        if (notpd) {
+            if (tid == 0) fb_rows[atomicAdd(fb_count, 1)] = u;   // not positive definite: the LU kernel redoes it
+        } else {
+            for (int c = tid; c < ld; c += C::NTHR) g[(int64_t)u * ld + c] = (c < f) ? gs[c] : 0.f;
+        }
+        u = un; lo = lon; d = dn;
+        __syncthreads();                                         // gs / flag are reused by the next row
+    }
+}
+
+template <int NFB>
+__global__ __launch_bounds__(256, 2) void solve_rowsplit_kernel(const int32_t* __restrict__ rows, int64_t count,
+                                                                const float* __restrict__ V, const float* __restrict__ biasv,
+                                                                const int64_t* __restrict__ indptr,
+                                                                const int32_t* __restrict__ indices,
+                                                                const float* __restrict__ vals, int f, int ld,
+                                                                float* __restrict__ g, int32_t* __restrict__ fb_rows,
+                                                                int32_t* __restrict__ fb_count, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sm = reinterpret_cast<float*>(smem_raw);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (wave) {
+        case 0: rs_body<NFB, 0>(sm, rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg); break;
+        case 1: rs_body<NFB, 1>(sm, rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg); break;
+        case 2: rs_body<NFB, 2>(sm, rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg); break;
+        default: rs_body<NFB, 3>(sm, rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg); break;
+    }
+}
+
+template <int NFB>
+static void launch_rowsplit_nfb(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
+                                const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
+                                int32_t* fb_count, hipStream_t st) {
+    using C = RsCfg<NFB>;
+    constexpr size_t lds = (size_t)C::TOTAL * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)solve_rowsplit_kernel<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    int64_t grid = 256 * 2 * 2;                                  // two resident workgroups per CU, two rounds
+    if (grid > count) grid = count;
+    hipLaunchKernelGGL((solve_rowsplit_kernel<NFB>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, rows, count, V, biasv, indptr,
+                       indices, vals, f, ld, g, fb_rows, fb_count, wmf_debug_flags);
+}
+
+int wmf_rowsplit_supported(int f) { return f > 144 && f <= 256; }
+
+int wmf_launch_rowsplit(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
+                        const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
+                        int32_t* fb_count, hipStream_t st) {
+    if (count <= 0) return 0;
+    switch ((f + 15) / 16) {
+#define C_(N) case N: launch_rowsplit_nfb<N>(rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, st); break;
+        C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
+#undef C_
+        default: return -1;
+    }
+    return 0;
+}

@@ -577,8 +577,13 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
         // f > 144: rows with more than 32 entries go to the workgroup-per-row kernel (wmf_wide.hip)
         if (!wmf_wide_supported(f)) return -1;
         WmfProfScope ps(WMF_SLOT_SOLVE_HEAVY, st);
-        if (wmf_launch_wide(pl->rows[WMF_BIN_GENERAL], pl->count[WMF_BIN_GENERAL], V, biasv, indptr, indices, vals, f, ld, g,
-                            pl->fallback_rows, pl->fallback_count, st)) return -1;
+        // f <= 256: four waves per row, tiles owned by block row (wmf_rowsplit.hip); f = 257 .. 272, or debug flag
+        // 1024: the run-time-indexed eight-wave kernel (wmf_wide.hip)
+        if (wmf_rowsplit_supported(f) && !(wmf_debug_flags & 1024)) {
+            if (wmf_launch_rowsplit(pl->rows[WMF_BIN_GENERAL], pl->count[WMF_BIN_GENERAL], V, biasv, indptr, indices, vals, f, ld,
+                                    g, pl->fallback_rows, pl->fallback_count, st)) return -1;
+        } else if (wmf_launch_wide(pl->rows[WMF_BIN_GENERAL], pl->count[WMF_BIN_GENERAL], V, biasv, indptr, indices, vals, f, ld,
+                                   g, pl->fallback_rows, pl->fallback_count, st)) return -1;
     }
     {
         // rows bounced by the other kernels (negative weights / not positive definite); count is on the device
