@@ -598,27 +598,30 @@ int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, floa
 // (t, e), whose k slot q then means k = 16 t + 4 q + e; the B operand is W[k][16 nb + r] read from
 // the LDS copy of W (row stride ldw = 4 mod 8 dwords keeps the two k rows of a 32-lane half on
 // different banks).  The sum over k is order independent, so this k permutation is free.
-template <int NFB, bool W_IN_LDS>
+// NB0 / NBW: this launch produces the NBW output blocks starting at block NB0 (all of them when the whole W fits
+// LDS; two or three column slices, each with its own launch, when it does not: f > 176).
+template <int NFB, bool W_IN_LDS, int NB0 = 0, int NBW = NFB>
 __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict__ in, int64_t m, int f, int ld,
                                                         const float* __restrict__ W, int set_col0_one,
                                                         float* __restrict__ out, float* __restrict__ col0_out,
                                                         int64_t nblocks16) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* Wl = reinterpret_cast<float*>(smem_raw);
-    constexpr int KP = 16 * NFB;          // padded K (rows of W) and padded N (cols of W)
-    constexpr int LDW = KP + 4;           // 4 mod 8 since KP is a multiple of 16
+    constexpr int KP = 16 * NFB;          // padded K (rows of W)
+    constexpr int NP = 16 * NBW;          // padded N of this slice (columns 16 NB0 .. of W)
+    constexpr int LDW = NP + 4;           // 4 mod 8 since NP is a multiple of 16
     const int tid = threadIdx.x;
     // nz[kb * NFB + nb] != 0 iff the 16 x 16 tile (kb, nb) of W has a non-zero entry.  Both matrices this kernel is
     // used with are triangular (L^-T, L^-1), so 36 of 81 tile products at f = 129 are skipped -- found from the data,
     // any W stays correct.
-    __shared__ int nz[NFB * NFB];
-    for (int e = tid; e < NFB * NFB; e += 512) nz[e] = 0;
+    __shared__ int nz[NFB * NBW];
+    for (int e = tid; e < NFB * NBW; e += 512) nz[e] = 0;
     __syncthreads();
     for (int e = tid; e < KP * LDW; e += 512) {
-        const int a = e / LDW, b = e % LDW;
-        const float v = (a < f && b < f) ? W[a * ld + b] : 0.f;
+        const int a = e / LDW, b = e % LDW, col = 16 * NB0 + b;
+        const float v = (a < f && b < NP && col < f) ? W[a * ld + col] : 0.f;
         if constexpr (W_IN_LDS) Wl[e] = v;
-        if (v != 0.f && b < KP) nz[(a >> 4) * NFB + (b >> 4)] = 1;    // benign race: every writer stores 1
+        if (v != 0.f) nz[(a >> 4) * NBW + (b >> 4)] = 1;              // benign race: every writer stores 1
     }
     __syncthreads();
     const int lane = tid & 63, wv = tid >> 6;
@@ -628,9 +631,9 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
         const int64_t row = blk * 16 + r;
         const bool rok = row < m;
         const float4* irow = reinterpret_cast<const float4*>(in + (rok ? row : 0) * (int64_t)ld);   // loads are unconditional
-        f32x4 acc[NFB];
+        f32x4 acc[NBW];
 #pragma unroll
-        for (int nb = 0; nb < NFB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NBW; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         float4 xn = irow[min(q, nch - 1)];
         if (!(rok && q < nch)) xn = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
@@ -642,18 +645,18 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
                 if (!(rok && c + 4 < nch)) xn = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             const int k0 = 4 * c;
-            int tnz[NFB];
+            int tnz[NBW];
 #pragma unroll
-            for (int nb = 0; nb < NFB; ++nb) tnz[nb] = __builtin_amdgcn_readfirstlane(nz[t * NFB + nb]);
+            for (int nb = 0; nb < NBW; ++nb) tnz[nb] = __builtin_amdgcn_readfirstlane(nz[t * NBW + nb]);
             float xe[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (k0 + e >= f) xe[e] = 0.f;
             if (set_col0_one && c == 0) {
-                if (rok && col0_out) col0_out[row] = xe[0];
+                if (rok && col0_out && NB0 == 0) col0_out[row] = xe[0];
                 xe[0] = rok ? 1.f : 0.f;
             }
 #pragma unroll
-            for (int nb = 0; nb < NFB; ++nb) {
+            for (int nb = 0; nb < NBW; ++nb) {
                 if (!tnz[nb]) continue;                      // wave-uniform: an all-zero tile of W
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
                     if constexpr (W_IN_LDS) {
                         b = Wl[k * LDW + 16 * nb + r];
                     } else {
-                        const int col = 16 * nb + r;
+                        const int col = 16 * (NB0 + nb) + r;
                         b = (k < f && col < f) ? W[k * ld + col] : 0.f;
                     }
                     acc[nb] = WMF_MFMA16(xe[e], b, acc[nb]);
@@ -676,13 +679,28 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
             if (orow < m) {
                 float* o = out + orow * (int64_t)ld;
 #pragma unroll
-                for (int nb = 0; nb < NFB; ++nb) {
-                    const int col = 16 * nb + r;
+                for (int nb = 0; nb < NBW; ++nb) {
+                    const int col = 16 * (NB0 + nb) + r;
                     if (col < ld) o[col] = acc[nb][reg];
                 }
             }
         }
     }
+}
+
+template <int NFB, int NB0, int NBW>
+static void launch_transform_slice(const float* in, int64_t m, int f, int ld, const float* W, int set_col0_one, float* out,
+                                   float* col0_out, int64_t grid, int64_t nblk, hipStream_t st) {
+    constexpr size_t lds = (size_t)16 * NFB * (16 * NBW + 4) * 4;
+    static_assert(lds <= 150 * 1024, "slice too wide");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)transform_kernel<NFB, true, NB0, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((transform_kernel<NFB, true, NB0, NBW>), dim3((unsigned)grid), dim3(512), lds, st, in, m, f, ld, W,
+                       set_col0_one, out, col0_out, nblk);
 }
 
 template <int NFB>
@@ -695,14 +713,19 @@ static void launch_transform_nfb(const float* in, int64_t m, int f, int ld, cons
     if (grid > 1024) grid = 1024;
     if (grid < 1) grid = 1;
     if constexpr (lds <= 150 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)transform_kernel<NFB, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds);
-            attr_set = true;
+        launch_transform_slice<NFB, 0, NFB>(in, m, f, ld, W, set_col0_one, out, col0_out, grid, nblk, st);
+    } else if (in != out) {
+        // W does not fit LDS (f > 176): two or three column slices of W, one launch each; every launch reads the
+        // input again (it may not alias the output) and writes its own output columns
+        constexpr int H = (NFB + 1) / 2;
+        if constexpr (H <= 8) {
+            launch_transform_slice<NFB, 0, H>(in, m, f, ld, W, set_col0_one, out, col0_out, grid, nblk, st);
+            launch_transform_slice<NFB, H, NFB - H>(in, m, f, ld, W, set_col0_one, out, col0_out, grid, nblk, st);
+        } else {
+            launch_transform_slice<NFB, 0, 6>(in, m, f, ld, W, set_col0_one, out, col0_out, grid, nblk, st);
+            launch_transform_slice<NFB, 6, 6>(in, m, f, ld, W, set_col0_one, out, col0_out, grid, nblk, st);
+            launch_transform_slice<NFB, 12, NFB - 12>(in, m, f, ld, W, set_col0_one, out, col0_out, grid, nblk, st);
         }
-        hipLaunchKernelGGL((transform_kernel<NFB, true>), dim3((unsigned)grid), dim3(512), lds, st, in, m, f, ld, W,
-                           set_col0_one, out, col0_out, nblk);
     } else {
         hipLaunchKernelGGL((transform_kernel<NFB, false>), dim3((unsigned)grid), dim3(512), 0, st, in, m, f, ld, W,
                            set_col0_one, out, col0_out, nblk);
