@@ -6,7 +6,7 @@
 // row bi.  Wave w owns rows {w, 7 - w, 8 + w, 15 - w}: 34 tiles each for NFB = 16 (136 accumulator registers), and
 // because w is a compile-time constant of the code a wave runs (four specialised copies of the row code, selected
 // once per workgroup), every accumulator index AND every LDS offset is an immediate:
-//   A. entries are staged 16 at a time through LDS; per k-step a wave reads the NFB fragments once (they are the
+//   A. entries are staged 16 at a time through two LDS buffers (one barrier per chunk); per k-step a wave reads the NFB fragments once (they are the
 //      B operands of all its tiles and, for its own four rows, the A operands) and issues its 34 MFMAs back to
 //      back:  tile(bi, bj) += frag[bi]^T (w frag[bj]);  the right-hand side y[bi] += p frag[bi] stays on the VALU.
 //   C. block LDL^T as in wmf_directw.hip: the owner of row p inverts tile (p, p) in its registers (16 DPP
@@ -32,10 +32,10 @@ struct RsCfg {
     static constexpr int RC = 16;                                 // staged entries per chunk
     static constexpr int PF = (RC * (FP / 4) + NTHR - 1) / NTHR;  // 16-byte pieces prefetched per thread and chunk
     // LDS carve (floats)
-    static constexpr int OFF_VS = 0;                              // [RC][LDV] staged factor rows
-    static constexpr int OFF_W = OFF_VS + RC * LDV;               // [RC] weights
-    static constexpr int OFF_P = OFF_W + RC;                      // [RC] w + 1 (0 past the end of the row)
-    static constexpr int OFF_PAN = OFF_P + RC;                    // [2][NFB][16][20]: {originals, W} of the pivot row, by block column
+    static constexpr int OFF_VS = 0;                              // [2][RC][LDV] staged factor rows, double buffered
+    static constexpr int OFF_W = OFF_VS + 2 * RC * LDV;           // [2][RC] weights
+    static constexpr int OFF_P = OFF_W + 2 * RC;                  // [2][RC] w + 1 (0 past the end of the row)
+    static constexpr int OFF_PAN = OFF_P + 2 * RC;                 // [2][NFB][16][20]: {originals, W} of the pivot row, by block column
     static constexpr int OFF_WV = OFF_PAN + 2 * NFB * 320;        // [16] w_p of the pivot row (+ spare)
     static constexpr int OFF_G = OFF_WV + 32;                     // [FP] solution
     static constexpr int OFF_FLAG = OFF_G + FP;                   // [4]
@@ -93,7 +93,7 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
             wpre = on ? wv : 0.f;
         }
     };
-    for (int e = tid; e < C::RC * C::LDV; e += C::NTHR) Vs[e] = 0.f;       // pad columns [ld, LDV) stay zero for good
+    for (int e = tid; e < 2 * C::RC * C::LDV; e += C::NTHR) Vs[e] = 0.f;   // pad columns [ld, LDV) stay zero for good
 
     int64_t it = blockIdx.x;
     int u = 0, d = 0;
@@ -115,22 +115,37 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
         float yacc[4] = {0.f, 0.f, 0.f, 0.f};                    // this lane's q share of y[16 row + r], per row slot
         if (tid == 0) flag[0] = 0;
 
-        // ---- A
-        for (int c = 0; c < nchunks; ++c) {
-            const int base = c * C::RC;
-            const int nrow = min(C::RC, d - base);
-            __syncthreads();                                     // everyone finished reading the previous chunk
+        // ---- A.  `pre` holds chunk 0 on entry (requested at the start, or during the previous row's elimination).
+        //      Two LDS buffers: chunk c + 1 is written while slower waves may still read chunk c, so one barrier per
+        //      chunk is enough, and the global loads of chunk c + 2 fly during the MFMAs of chunk c + 1.
+        auto stage = [&](int c) {                                // registers -> LDS buffer c & 1
+            float* vb = Vs + (c & 1) * (C::RC * C::LDV);
+            const int nrow = min(C::RC, d - c * C::RC);
 #pragma unroll
             for (int i = 0; i < C::PF; ++i)
-                if (pj[i] < C::RC) *reinterpret_cast<float4*>(&Vs[pj[i] * C::LDV + 4 * pc[i]]) = pre[i];   // zeros beyond nrow
-            if (tid < C::RC) { wsm[tid] = wpre; psm[tid] = (tid < nrow) ? wpre + 1.f : 0.f; }
+                if (pj[i] < C::RC) *reinterpret_cast<float4*>(&vb[pj[i] * C::LDV + 4 * pc[i]]) = pre[i];   // zeros beyond nrow
+            if (tid < C::RC) { wsm[(c & 1) * C::RC + tid] = wpre; psm[(c & 1) * C::RC + tid] = (tid < nrow) ? wpre + 1.f : 0.f; }
+        };
+        auto request = [&](int c) {                              // chunk c of this row, or the next row's first chunk
+            if (c < nchunks) load_chunk(lo, d, c * C::RC);
+            else if (itn < count) load_chunk(lon, dn, 0);
+        };
+        if (nchunks > 0) {
+            stage(0);
             __syncthreads();
-            if (c + 1 < nchunks) load_chunk(lo, d, base + C::RC);
-            else if (itn < count) load_chunk(lon, dn, 0);        // the next row's first chunk flies during the elimination
+            request(1);
+        } else {
+            request(0);                                          // nchunks == 0: straight to the next row
+        }
+        for (int c = 0; c < nchunks; ++c) {
+            const int nrow = min(C::RC, d - c * C::RC);
+            const float* vb = Vs + (c & 1) * (C::RC * C::LDV);
+            const float* wb = wsm + (c & 1) * C::RC;
+            const float* pb = psm + (c & 1) * C::RC;
             const int nsteps = (dbg & 2) ? 0 : (nrow + 3) >> 2;  // dbg: timing ablations (wmf_debug_set_flags)
             for (int ks = 0; ks < nsteps; ++ks) {
-                const float wq = wsm[4 * ks + q], pq = psm[4 * ks + q];
-                const float* vrow = Vs + (4 * ks + q) * C::LDV + r;
+                const float wq = wb[4 * ks + q], pq = pb[4 * ks + q];
+                const float* vrow = vb + (4 * ks + q) * C::LDV + r;
                 float fw[NFB];                                   // w * fragment: the B operands of every tile of column bj
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) fw[fb] = vrow[16 * fb] * wq;
@@ -148,8 +163,12 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
                     }
                 }
             }
+            if (c + 1 < nchunks) {
+                stage(c + 1);
+                __syncthreads();
+                request(c + 2);
+            }
         }
-        if (nchunks == 0 && itn < count) load_chunk(lon, dn, 0);
 
         // ---- C: block elimination
         bool ok = true;
