@@ -1,4 +1,4 @@
-// Rows with more than 32 stored entries when 144 < f <= 256 (k = 256 without biases, and every width between):
+// Rows with more than 32 stored entries when 144 < f <= 257 (k = 256 with or without biases, and the widths between):
 // the f x f whitened system  (I + V_u^T D V_u) g = V_u^T p  is too big for one wave's accumulators
 // (wmf_directw.hip), so FOUR waves share it BY BLOCK ROWS.  Reference arithmetic: RecModel/wmf_model.py:233-239.
 //
@@ -16,21 +16,24 @@
 //      computes while the other waits for its pivot.
 //   D. g_p = w_p - sum_{j>p} W_pj g_j: the owner of row p has every W_pj in registers; rows are finished from the
 //      last to the first, one barrier each.
+// BORDER (f = 16 NFB + 1, k = 16 NFB with biases): the last column is a border of the NFB-block system exactly as in
+// wmf_directw.hip -- a second right-hand side through the elimination, a scalar last pivot.
 // A non-positive pivot bounces the row to the pivoted LU kernel (wmf_wide.hip).  Compared with the run-time-indexed
-// kernel in wmf_wide.hip (still used for f > 256): no LDS operand reads inside the MFMA stream beyond the shared
+// kernel in wmf_wide.hip (still used for 257 < f <= 272): no LDS operand reads inside the MFMA stream beyond the shared
 // fragments, no register or scalar spills, two barriers per pivot instead of three.
 #include "wmf_common.h"
 #include "wmf_internal.h"
 
 #include <utility>
 
-template <int NFB>
+template <int NFB, bool BORDER = false>
 struct RsCfg {
     static constexpr int NW = 4, NTHR = 256;
     static constexpr int FP = 16 * NFB;
-    static constexpr int LDV = (FP % 32 == 16) ? FP : FP + 16;   // = 16 (mod 32): the two k rows of a half wave hit disjoint banks
+    // row stride = 16 (mod 32): the two k rows of a half wave hit disjoint banks; BORDER needs room for column FP
+    static constexpr int LDV = (FP % 32 == 16) ? (BORDER ? FP + 32 : FP) : FP + 16;
     static constexpr int RC = 16;                                 // staged entries per chunk
-    static constexpr int PF = (RC * (FP / 4) + NTHR - 1) / NTHR;  // 16-byte pieces prefetched per thread and chunk
+    static constexpr int PF = (RC * (FP / 4 + (BORDER ? 1 : 0)) + NTHR - 1) / NTHR;  // 16-byte pieces prefetched per thread and chunk
     // LDS carve (floats)
     static constexpr int OFF_VS = 0;                              // [2][RC][LDV] staged factor rows, double buffered
     static constexpr int OFF_W = OFF_VS + 2 * RC * LDV;           // [2][RC] weights
@@ -38,7 +41,8 @@ struct RsCfg {
     static constexpr int OFF_PAN = OFF_P + 2 * RC;                 // [2][NFB][16][20]: {originals, W} of the pivot row, by block column
     static constexpr int OFF_WV = OFF_PAN + 2 * NFB * 320;        // [16] w_p of the pivot row (+ spare)
     static constexpr int OFF_G = OFF_WV + 32;                     // [FP] solution
-    static constexpr int OFF_FLAG = OFF_G + FP;                   // [4]
+    static constexpr int OFF_WB = OFF_G + FP;                     // BORDER: [FP] w^b_p of every pivot row, then [8] scalars
+    static constexpr int OFF_FLAG = OFF_WB + (BORDER ? FP + 8 : 0);   // [4]
     static constexpr int TOTAL = OFF_FLAG + 4;
 };
 
@@ -52,14 +56,16 @@ template <int NFB, int W> __device__ __host__ constexpr int rs_base(int s) {
 }
 template <int NFB, int W> __device__ __host__ constexpr int rs_ntiles() { return rs_base<NFB, W>(4); }
 
-template <int NFB, int W>
+template <int NFB, int W, bool BORDER>
 __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* __restrict__ rows, int64_t count,
                                         const float* __restrict__ V, const float* __restrict__ biasv,
                                         const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                         const float* __restrict__ vals, int f, int ld, float* __restrict__ g,
                                         int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int dbg) {
-    using C = RsCfg<NFB>;
+    using C = RsCfg<NFB, BORDER>;
     constexpr int NT = rs_ntiles<NFB, W>();
+    float* Wball = sm + C::OFF_WB;                               // BORDER only
+    float* bsc = sm + C::OFF_WB + C::FP;                         // BORDER: [0] sum_p b_p^T w^b_p, [1] sum_p b_p^T w^y_p
     float* Vs = sm + C::OFF_VS; float* wsm = sm + C::OFF_W; float* psm = sm + C::OFF_P;
     float* Pan = sm + C::OFF_PAN; float* Wv = sm + C::OFF_WV; float* gs = sm + C::OFF_G;
     int* flag = reinterpret_cast<int*>(sm + C::OFF_FLAG);
@@ -113,7 +119,9 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         float yacc[4] = {0.f, 0.f, 0.f, 0.f};                    // this lane's q share of y[16 row + r], per row slot
-        if (tid == 0) flag[0] = 0;
+        float bacc[4] = {0.f, 0.f, 0.f, 0.f};                    // BORDER: the same for the border column b
+        float cacc = 0.f, eacc = 0.f;                            // BORDER: c and e, this lane's q share (every wave has them)
+        if (tid == 0) { flag[0] = 0; if constexpr (BORDER) { bsc[0] = 0.f; bsc[1] = 0.f; } }
 
         // ---- A.  `pre` holds chunk 0 on entry (requested at the start, or during the previous row's elimination).
         //      Two LDS buffers: chunk c + 1 is written while slower waves may still read chunk c, so one barrier per
@@ -149,12 +157,20 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
                 float fw[NFB];                                   // w * fragment: the B operands of every tile of column bj
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) fw[fb] = vrow[16 * fb] * wq;
+                float bw = 0.f;
+                if constexpr (BORDER) {
+                    const float bf = vb[(4 * ks + q) * C::LDV + 16 * NFB];   // feature f - 1 of this lane's entry (same for all r)
+                    bw = bf * wq;
+                    cacc += bf * bw;
+                    eacc += bf * pq;
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int bi = rs_row<W>(s);
                     if (bi < NFB) {
                         const float fa = vrow[16 * bi];          // this row's fragment again (A operand): an LDS read is cheaper than a register
                         yacc[s] += fa * pq;
+                        if constexpr (BORDER) bacc[s] += fa * bw;
 #pragma unroll
                         for (int bj = bi; bj < NFB; ++bj) {
                             const int t = rs_base<NFB, W>(s) + bj - bi;
@@ -172,6 +188,7 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
 
         // ---- C: block elimination
         bool ok = true;
+        float tbv = 0.f;                                         // BORDER: the solution's last component
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (rs_row<W>(s) < NFB) {
@@ -195,6 +212,23 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
                 if (r == 0) {
                     *reinterpret_cast<float4*>(wv_out + 4 * q) = make_float4(wv0, wv1, wv2, wv3);
                     *reinterpret_cast<float4*>(gs + 16 * bi + 4 * q) = make_float4(wv0, wv1, wv2, wv3);   // start of the backward pass
+                }
+                if constexpr (BORDER) {                          // the border column rides along like a second right-hand side
+                    float bp = bacc[S];
+                    bp += __shfl_xor(bp, 16);
+                    bp += __shfl_xor(bp, 32);
+                    float wb0 = X[0] * bp, wb1 = X[1] * bp, wb2 = X[2] * bp, wb3 = X[3] * bp;
+                    wmf_row16_sum4(wb0, wb1, wb2, wb3);
+                    if (r == 0) {
+                        *reinterpret_cast<float4*>(wv_out + 16 + 4 * q) = make_float4(wb0, wb1, wb2, wb3);
+                        *reinterpret_cast<float4*>(Wball + 16 * bi + 4 * q) = make_float4(wb0, wb1, wb2, wb3);
+                    }
+                    const float b0v = __shfl(bp, 4 * q), b1v = __shfl(bp, 4 * q + 1), b2v = __shfl(bp, 4 * q + 2), b3v = __shfl(bp, 4 * q + 3);
+                    float cc = b0v * wb0 + b1v * wb1 + b2v * wb2 + b3v * wb3;      // this q group's rows of b_p^T w^b_p
+                    float ec = b0v * wv0 + b1v * wv1 + b2v * wv2 + b3v * wv3;
+                    cc += __shfl_xor(cc, 16); cc += __shfl_xor(cc, 32);
+                    ec += __shfl_xor(ec, 16); ec += __shfl_xor(ec, 32);
+                    if (lane == 0) { bsc[0] += cc; bsc[1] += ec; }   // one pivot owner at a time, barriers in between
                 }
 #pragma unroll
                 for (int bj = bi + 1; bj < NFB; ++bj) {
@@ -224,6 +258,8 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
                 else if (p == rs_row<W>(3)) pivot_row(std::integral_constant<int, 3>{}, p, P1, P2, wvp);
                 __syncthreads();                                 // panels of row p published
                 const float4 w4 = *reinterpret_cast<const float4*>(wvp + 4 * q);
+                float4 wb4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (BORDER) wb4 = *reinterpret_cast<const float4*>(wvp + 16 + 4 * q);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     constexpr int dummy = 0; (void)dummy;
@@ -233,6 +269,7 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
 #pragma unroll
                         for (int e = 0; e < 4; ++e) a[e] = -P1[bi * 320 + (4 * q + e) * 20 + r];
                         yacc[s] += a[0] * w4.x + a[1] * w4.y + a[2] * w4.z + a[3] * w4.w;
+                        if constexpr (BORDER) bacc[s] += a[0] * wb4.x + a[1] * wb4.y + a[2] * wb4.z + a[3] * wb4.w;
 #pragma unroll
                         for (int bj = bi; bj < NFB; ++bj) {
                             const int t = rs_base<NFB, W>(s) + bj - bi;
@@ -243,8 +280,21 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
                 }
                 __syncthreads();                                 // everyone has read the panels: the next pivot may overwrite them
             }
+            float tb = 0.f;                                      // BORDER: the last unknown
+            if constexpr (BORDER) {
+                cacc += __shfl_xor(cacc, 16); cacc += __shfl_xor(cacc, 32);
+                eacc += __shfl_xor(eacc, 16); eacc += __shfl_xor(eacc, 32);
+                const float piv = 1.f + cacc - bsc[0];           // identity + c - sum_p b_p^T w^b_p (the last pivot's barrier made bsc final)
+                if (!(piv > 1e-20f)) ok = false;
+                tb = (eacc - bsc[1]) * __builtin_amdgcn_rcpf(piv);
+                tbv = tb;
+            }
             if (!ok && lane == 0) flag[0] = 1;
             __syncthreads();
+            if constexpr (BORDER) {                              // the backward pass starts from w^y_p - t w^b_p
+                for (int c = tid; c < 16 * NFB; c += C::NTHR) gs[c] -= tb * Wball[c];
+                __syncthreads();
+            }
             // ---- D: rows from the last to the first; gs[16 p ..] holds w_p until row p is finished
 #pragma unroll 1
             for (int p = NFB - 1; p >= 0; --p) {
@@ -280,14 +330,18 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
         if (notpd) {
             if (tid == 0) fb_rows[atomicAdd(fb_count, 1)] = u;   // not positive definite: the LU kernel redoes it
         } else {
-            for (int c = tid; c < ld; c += C::NTHR) g[(int64_t)u * ld + c] = (c < f) ? gs[c] : 0.f;
+            for (int c = tid; c < ld; c += C::NTHR) {
+                float v = (c < f) ? gs[c < 16 * NFB ? c : 0] : 0.f;
+                if constexpr (BORDER) { if (c == 16 * NFB) v = tbv; else if (c > 16 * NFB) v = 0.f; }
+                g[(int64_t)u * ld + c] = v;
+            }
         }
         u = un; lo = lon; d = dn;
         __syncthreads();                                         // gs / flag are reused by the next row
     }
 }
 
-template <int NFB>
+template <int NFB, bool BORDER>
 __global__ __launch_bounds__(256, 2) void solve_rowsplit_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                                 const float* __restrict__ V, const float* __restrict__ biasv,
                                                                 const int64_t* __restrict__ indptr,
@@ -299,38 +353,49 @@ __global__ __launch_bounds__(256, 2) void solve_rowsplit_kernel(const int32_t* _
     float* sm = reinterpret_cast<float*>(smem_raw);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wave) {
-        case 0: rs_body<NFB, 0>(sm, rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg); break;
-        case 1: rs_body<NFB, 1>(sm, rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg); break;
-        case 2: rs_body<NFB, 2>(sm, rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg); break;
-        default: rs_body<NFB, 3>(sm, rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg); break;
+        case 0: rs_body<NFB, 0, BORDER>(sm, rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg); break;
+        case 1: rs_body<NFB, 1, BORDER>(sm, rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg); break;
+        case 2: rs_body<NFB, 2, BORDER>(sm, rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg); break;
+        default: rs_body<NFB, 3, BORDER>(sm, rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg); break;
     }
 }
 
-template <int NFB>
+template <int NFB, bool BORDER>
 static void launch_rowsplit_nfb(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                                 const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
                                 int32_t* fb_count, hipStream_t st) {
-    using C = RsCfg<NFB>;
+    using C = RsCfg<NFB, BORDER>;
     constexpr size_t lds = (size_t)C::TOTAL * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)solve_rowsplit_kernel<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)solve_rowsplit_kernel<NFB, BORDER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
         attr_set = true;
     }
     int64_t grid = 256 * 2 * 2;                                  // two resident workgroups per CU, two rounds
     if (grid > count) grid = count;
-    hipLaunchKernelGGL((solve_rowsplit_kernel<NFB>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, rows, count, V, biasv, indptr,
-                       indices, vals, f, ld, g, fb_rows, fb_count, wmf_debug_flags);
+    hipLaunchKernelGGL((solve_rowsplit_kernel<NFB, BORDER>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, rows, count, V, biasv,
+                       indptr, indices, vals, f, ld, g, fb_rows, fb_count, wmf_debug_flags);
 }
 
-int wmf_rowsplit_supported(int f) { return f > 144 && f <= 256; }
+// 144 < f <= 256, and f = 16 m + 1 up to 257 (k = 16 m with biases: m blocks and a border column)
+int wmf_rowsplit_supported(int f) { return f > 144 && (f <= 256 || f == 257); }
 
 int wmf_launch_rowsplit(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                         const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
                         int32_t* fb_count, hipStream_t st) {
     if (count <= 0) return 0;
+    if (f % 16 == 1 && f / 16 >= 10) {
+        switch (f / 16) {
+#define C_(N) case N: launch_rowsplit_nfb<N, true>(rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, st); break;
+            C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
+#undef C_
+            default: return -1;
+        }
+        return 0;
+    }
     switch ((f + 15) / 16) {
-#define C_(N) case N: launch_rowsplit_nfb<N>(rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, st); break;
+#define C_(N) case N: launch_rowsplit_nfb<N, false>(rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, st); break;
         C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
 #undef C_
         default: return -1;

@@ -195,7 +195,9 @@ def ragged_matrix(n, m, seed, dtype=np.float32):
                                     (256, False), (256, True), (150, False), (200, True),
                                     # f = 16 m + 1: the heavy-row kernel treats the last column as a border of an m-block system
                                     # (m = 1, 2, 6), except when m + 1 is a multiple of 4 (m = 3, 7: plain m + 1 blocks)
-                                    (16, True), (32, True), (96, True), (48, True), (112, True)])
+                                    (16, True), (32, True), (96, True), (48, True), (112, True),
+                                    # the same border in the four-waves-per-row kernel (144 < f <= 257); 240: odd block count
+                                    (176, True), (240, True)])
 def test_half_step_vs_oracle_all_degree_classes(WMF, k, bias):
     n, m_items = (2500, 600) if k <= 128 else (900, 500)     # the NumPy oracle is O(f^3) per row
     C = ragged_matrix(n, m_items, seed=k + bias)
