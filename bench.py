@@ -271,7 +271,11 @@ def main():
         "config": {"workload": f"{args.config}: WMF k={k}{'+bias' if bias else ''}, {n_users}x{n_items} CSR, "
                                f"{nnz} nnz, alpha-log confidence, gamma={gamma}, zipf_a={args.zipf}",
                    "n_users": n_users, "n_items": n_items, "nnz": nnz, "k": k, "bias": bias,
-                   "sharding": f"users+items round-robin over {world} GPU(s), {len(eng.chunk_bounds['users'])} chunk(s) per side"},
+                   "sharding": f"users+items round-robin over {world} GPU(s); exchange users: "
+                               f"{'reduce-scatter of partial systems' if eng.reduce['users'] else 'all-gather'} in "
+                               f"{len(eng.chunk_bounds['users'])} chunk(s), items: "
+                               f"{'reduce-scatter of partial systems' if eng.reduce['items'] else 'all-gather'} in "
+                               f"{len(eng.chunk_bounds['items'])} chunk(s)"},
         "nnz_per_s": 2.0 * nnz * args.steps / elapsed,
         "epoch_algorithmic_GBps": epoch_bytes * args.steps / elapsed / 1e9,
         "epoch_hbm_frac": epoch_bytes * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),

@@ -152,6 +152,26 @@ int wmf_spmm_rows(const float* V, const int64_t* indptr, const int32_t* indices,
  * device.  wmf_model.py:119-123. */
 int wmf_confidence_transform(float* values, int64_t nnz, double alpha, double beta, int mode, void* stream);
 
+/* ---- partial systems for a reduce-scatter exchange (f <= 144) ------------------------------------
+ * When the rows being updated are few and the fixed side is large (many users, few items), gathering the fixed
+ * side's factors costs more than exchanging the rows' accumulated systems: every rank accumulates, for EVERY row,
+ * the part of  V_u^T D V_u  and  V_u^T p  that its own slice of the fixed side contributes, the partial systems are
+ * summed over ranks (reduce-scatter), and each rank eliminates the rows it owns.  Same arithmetic as
+ * wmf_solve_rows' heavy-row kernel (wmf_model.py:233-239), split at the sum over stored entries.
+ *   wmf_partial_row_floats(f)  floats per row of a partial-system buffer (0: width not supported);
+ *   wmf_accumulate_rows        partial[i] = system of CSR row i over this rank's entries (zeros for an empty row);
+ *                              degrees = int32[n] device, indptr[i + 1] - indptr[i]; bias_fixed != NULL needs
+ *                              w_eff_workspace (float[nnz], device) for values - bias_fixed[indices];
+ *   wmf_eliminate_rows         g[i] = (I + A_i)^-1 y_i from the SUMMED buffer; a row whose system is not positive
+ *                              definite is counted in fail_count (there is no CSR here to hand to the pivoted
+ *                              fallback); scratch = int32[n] device. */
+int64_t wmf_partial_row_floats(int f);
+int wmf_accumulate_rows(const float* V, const float* bias_fixed, const int64_t* indptr, const int32_t* degrees,
+                        const int32_t* indices, const float* values, int64_t n, int64_t nnz, int f, int ld,
+                        float* partial, float* w_eff_workspace, void* stream);
+int wmf_eliminate_rows(float* partial, int64_t n, int f, int ld, float* g, int32_t* fail_count, int32_t* scratch,
+                       void* stream);
+
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------------- */
 /* When enabled, every kernel launch of the device-level entry points is bracketed by HIP events
  * on its own stream.  wmf_profile_read() waits for them and ADDS, per kernel slot, the elapsed

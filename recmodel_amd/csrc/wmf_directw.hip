@@ -107,6 +107,7 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
     int64_t it = blockIdx.x;
     auto item = [&](int64_t i, int& u_, int64_t& lo_, int& d_) {   // work item i: a row (MODE 0, 2) or a segment (MODE 1)
         if constexpr (MODE == 1) { u_ = 0; lo_ = seg_lo[i]; d_ = seg_d[i]; }
+        else if constexpr (MODE == 2) { u_ = rows ? rows[i] : (int)i; lo_ = 0; d_ = 0; }     // rows == NULL: row i itself
         else { u_ = rows[i]; lo_ = indptr[u_]; d_ = (int)(indptr[u_ + 1] - lo_); }
     };
     if (it < count) item(it, u, lo, d);
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
             continue;
         }
         if constexpr (MODE == 2) {                               // sum the segments of heavy row `it` in a fixed order
-            for (int sgm = seg_first[it]; sgm < seg_first[it + 1]; ++sgm) {
+            const int sg0 = seg_first ? seg_first[it] : (int)it, sg1 = seg_first ? seg_first[it + 1] : (int)it + 1;
+            for (int sgm = sg0; sgm < sg1; ++sgm) {
                 const float* in = partial + sgm * (int64_t)WMF_DW_PARTIAL(NFB, BORDER);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
@@ -356,13 +358,83 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
     }
 }
 
+// Partial systems for the reduce-scatter exchange (engine.py, "reduce mode"): MODE 1 over every row of a CSR (one
+// segment per row, slot = row) and MODE 2 over a buffer of summed partial systems (one slot per row, row = slot).
+template <int NFB, bool BORDER>
+static void launch_accumulate_nfb(const float* V, const int64_t* indptr, const int32_t* degrees, const int32_t* indices,
+                                  const float* vals, int64_t n, int f, int ld, float* partial, hipStream_t st) {
+    const int64_t cap = 256 * 4 * DwCfg<NFB>::OCC * 3;
+    hipLaunchKernelGGL((solve_directw_kernel<NFB, 1, BORDER>), dim3((unsigned)(n < cap ? n : cap)), dim3(64), 0, st, nullptr, n, V,
+                       nullptr, indptr, indices, vals, f, ld, nullptr, nullptr, nullptr, wmf_debug_flags & ~3, indptr, degrees,
+                       nullptr, partial);
+}
+template <int NFB, bool BORDER>
+static void launch_eliminate_nfb(float* partial, int64_t n, int f, int ld, float* g, int32_t* fb_rows, int32_t* fail_count,
+                                 hipStream_t st) {
+    const int64_t cap = 256 * 4 * DwCfg<NFB>::OCC * 3;
+    hipLaunchKernelGGL((solve_directw_kernel<NFB, 2, BORDER>), dim3((unsigned)(n < cap ? n : cap)), dim3(64), 0, st, nullptr, n,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, f, ld, g, fb_rows, fail_count, wmf_debug_flags & ~3, nullptr,
+                       nullptr, nullptr, partial);
+}
+static bool dw_border(int f) { return f > 16 && f % 16 == 1 && (f / 16) % 4 != 3 && !(wmf_debug_flags & 256); }
+
+int64_t wmf_directw_partial_floats(int f) {
+    if (f < 1 || f > 144) return 0;
+    const int64_t nfb = dw_border(f) ? f / 16 : (f + 15) / 16;
+    return (nfb * (nfb + 1) / 2 * 4 + nfb + (dw_border(f) ? nfb + 2 : 0)) * 64;
+}
+
+int wmf_launch_accumulate(const float* V, const int64_t* indptr, const int32_t* degrees, const int32_t* indices,
+                          const float* vals, int64_t n, int f, int ld, float* partial, hipStream_t st) {
+    if (n <= 0) return 0;
+    if (f > 144) return -1;
+    if (dw_border(f)) {
+        switch (f / 16) {
+#define C_(N) case N: launch_accumulate_nfb<N, true>(V, indptr, degrees, indices, vals, n, f, ld, partial, st); break;
+            C_(1) C_(2) C_(4) C_(5) C_(6) C_(8)
+#undef C_
+            default: return -1;
+        }
+        return 0;
+    }
+    switch ((f + 15) / 16) {
+#define C_(N) case N: launch_accumulate_nfb<N, false>(V, indptr, degrees, indices, vals, n, f, ld, partial, st); break;
+        C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9)
+#undef C_
+        default: return -1;
+    }
+    return 0;
+}
+
+int wmf_launch_eliminate(float* partial, int64_t n, int f, int ld, float* g, int32_t* fb_rows, int32_t* fail_count,
+                         hipStream_t st) {
+    if (n <= 0) return 0;
+    if (f > 144) return -1;
+    if (dw_border(f)) {
+        switch (f / 16) {
+#define C_(N) case N: launch_eliminate_nfb<N, true>(partial, n, f, ld, g, fb_rows, fail_count, st); break;
+            C_(1) C_(2) C_(4) C_(5) C_(6) C_(8)
+#undef C_
+            default: return -1;
+        }
+        return 0;
+    }
+    switch ((f + 15) / 16) {
+#define C_(N) case N: launch_eliminate_nfb<N, false>(partial, n, f, ld, g, fb_rows, fail_count, st); break;
+        C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9)
+#undef C_
+        default: return -1;
+    }
+    return 0;
+}
+
 int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int f, int ld, float* g, hipStream_t st) {
     if (pl->count[WMF_BIN_MFMA] <= 0) return 0;
     const int dbg = wmf_debug_flags;
     // k = 16 m with biases: m blocks and a border column.  The row stream must deliver the border feature as its own
     // dword block (lane 0), which it does unless m + 1 is a multiple of 4 (then all blocks are 16-byte pieces).
-    if (f > 16 && f % 16 == 1 && (f / 16) % 4 != 3 && !(dbg & 256)) {
+    if (dw_border(f)) {
         switch (f / 16) {
 #define C_(N) case N: launch_directw_nfb<N, true>(pl, V, biasv, indptr, indices, vals, f, ld, g, dbg, st); break;
             C_(1) C_(2) C_(4) C_(5) C_(6) C_(8)

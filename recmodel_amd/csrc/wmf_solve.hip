@@ -479,6 +479,17 @@ __global__ __launch_bounds__(256) void bias_adjust_kernel(const float* __restric
         w_eff[j] = vals[j] - biasv[indices[j]];
 }
 
+void wmf_launch_bias_adjust(const float* vals, const int32_t* indices, const float* biasv, int64_t nnz, float* w_eff,
+                            hipStream_t st) {
+    if (nnz <= 0) return;
+    int64_t grid = (nnz + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    WmfProfScope ps(WMF_SLOT_OTHER, st);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(indices)) & 15) == 0;
+    hipLaunchKernelGGL(bias_adjust_kernel, dim3((unsigned)grid), dim3(256), 0, st, vals, indices, biasv, nnz,
+                       aligned ? (nnz >> 2) : (int64_t)0, w_eff);
+}
+
 // ------------------------------------------------------------------------------------- launchers
 template <int NCH>
 static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
@@ -541,12 +552,7 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
     if (biasv) {                                                       // fold the fixed side's biases into the weights once
         wmf_plan* plm = const_cast<wmf_plan*>(pl);
         if (!plm->w_eff && hipMalloc((void**)&plm->w_eff, (size_t)nnz * sizeof(float)) != hipSuccess) return -2;
-        int64_t grid = (nnz + 255) / 256;
-        if (grid > 8192) grid = 8192;
-        WmfProfScope ps(WMF_SLOT_OTHER, st);
-        const bool aligned = ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(indices)) & 15) == 0;
-        hipLaunchKernelGGL(bias_adjust_kernel, dim3((unsigned)grid), dim3(256), 0, st, vals, indices, biasv, nnz,
-                           aligned ? (nnz >> 2) : (int64_t)0, plm->w_eff);
+        wmf_launch_bias_adjust(vals, indices, biasv, nnz, plm->w_eff, st);
         vals = plm->w_eff;
         biasv = nullptr;
     }

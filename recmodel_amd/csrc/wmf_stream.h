@@ -39,7 +39,7 @@ struct WmfRowStream {
                                                const float* __restrict__ vals, int lane, int slot) {
         const int j = 64 * c + lane;
         const float mask = j < d ? 1.f : 0.f;
-        const int64_t e = lo + max(min(j, d - 1), 0);
+        const int64_t e = d > 0 ? lo + max(min(j, d - 1), 0) : 0;   // d == 0 (a row without entries): entry 0, weight 0
         const int idx = indices[e];
         const float wv = vals[e];
         if (slot == 0) { idxB[0] = idx; wB[0] = wv * mask; pB[0] = (wv + 1.f) * mask; }

@@ -23,6 +23,15 @@ gathered matrix itself -- a streaming pass at HBM speed, W times redundant, inst
 transfer over xGMI.  The gathered matrix is chunk-major so that every all-gather writes one contiguous
 range: with local index j = i // W in chunk c = j // chunk_len (chunk start s_c, length len_c), the
 *position* of id i is  W * s_c + (i % W) * len_c + (j - s_c).  With one rank this is the identity.
+
+Reduce mode.  When the side being updated is small and the fixed side large (few items, many users), the all-gather
+of the fixed side is the wrong exchange: a rank's block crosses each of its xGMI links whole.  Instead every rank
+accumulates, for EVERY row of the small side, the partial normal equations contributed by its own slice of the fixed
+side (C-ABI wmf_accumulate_rows), the partial systems are summed with a reduce-scatter -- chunk by chunk, the
+exchange of one chunk behind the accumulation of the next -- and each rank eliminates the rows it owns
+(wmf_eliminate_rows).  Per link that is rows_per_rank x (f(f+1)/2 + f) floats instead of rows_per_rank_of_the_fixed_side
+x f; the engine picks the mode per side from exactly that comparison (REDUCE_GAIN), and a side whose only consumer runs
+in reduce mode is not gathered at all until somebody asks for it (get_factors).
 """
 import ctypes
 import os
@@ -85,6 +94,16 @@ class HipKernels:
         _lib.check(self.lib.wmf_solve_rows(plan, _ptr(V), _ptr(bias_vec), _ptr(indptr), _ptr(indices), _ptr(values), n, f, ld,
                                            _ptr(g), _ptr(fail), _stream()))
 
+    def partial_row_floats(self, f):
+        return int(self.lib.wmf_partial_row_floats(f))
+
+    def accumulate_rows(self, V, bias_vec, indptr, degrees, indices, values, n, nnz, f, ld, partial, w_eff):
+        _lib.check(self.lib.wmf_accumulate_rows(_ptr(V), _ptr(bias_vec), _ptr(indptr), _ptr(degrees), _ptr(indices), _ptr(values),
+                                                n, nnz, f, ld, _ptr(partial), _ptr(w_eff), _stream()))
+
+    def eliminate_rows(self, partial, n, f, ld, g, fail, scratch):
+        _lib.check(self.lib.wmf_eliminate_rows(_ptr(partial), n, f, ld, _ptr(g), _ptr(fail), _ptr(scratch), _stream()))
+
     def spmm_rows(self, V, indptr, indices, values, n, f, ld, g):
         _lib.check(self.lib.wmf_spmm_rows(_ptr(V), _ptr(indptr), _ptr(indices), _ptr(values), n, f, ld, _ptr(g), _stream()))
 
@@ -135,6 +154,7 @@ def coo_to_csr(rows, cols, vals, n_rows):
 
 
 MIN_CHUNK_ROWS = 32768          # default chunking never makes chunks smaller than this
+REDUCE_GAIN = 0.8               # reduce mode when its bytes per link are below this fraction of the all-gather's
 
 
 def gathered_positions(ids, world, rows_per_rank, chunk_len):
@@ -149,7 +169,8 @@ def gathered_positions(ids, world, rows_per_rank, chunk_len):
 class AlsEngine:
     """Weighted-ALS state of one rank: factor blocks, whitened gathers, CSR shards."""
 
-    def __init__(self, n_users, n_items, dim, bias, gamma, device=None, group=None, kernels=None, chunks=None):
+    def __init__(self, n_users, n_items, dim, bias, gamma, device=None, group=None, kernels=None, chunks=None,
+                 reduce_mode=None):
         self.K = kernels if kernels is not None else HipKernels()     # raises without a GPU / built library
         self.lib = getattr(self.K, "lib", None)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -166,6 +187,19 @@ class AlsEngine:
         W = self.world
         self.rpr = {s: (self.n[s] + W - 1) // W for s in self.n}            # rows per rank (padded)
         self.n_local = {s: len(range(self.rank, self.n[s], W)) for s in self.n}
+        # exchange mode per updated side (module docstring): "reduce" = accumulate everywhere + reduce-scatter, else gather
+        pr = self.K.partial_row_floats(self.f) if hasattr(self.K, "partial_row_floats") else 0
+        forced = os.environ.get("WMF_REDUCE") if reduce_mode is None else ("1" if reduce_mode else "0")
+        self.reduce = {}
+        for s in self.n:
+            o = "items" if s == "users" else "users"
+            gain = W > 1 and pr > 0 and self.rpr[s] * pr < REDUCE_GAIN * self.rpr[o] * self.ld
+            self.reduce[s] = W > 1 and pr > 0 and (forced == "1" or (forced is None and gain))
+        if self.reduce["users"] and self.reduce["items"]:
+            # both at once would leave nobody holding a whole side; keep the one that saves more
+            keep = "items" if self.rpr["items"] <= self.rpr["users"] else "users"
+            self.reduce = {s: s == keep for s in self.n}
+        self.pr = pr
         auto_chunks = chunks is None and "WMF_CHUNKS" not in os.environ
         if chunks is None:
             chunks = int(os.environ.get("WMF_CHUNKS", "4")) if W > 1 else 1
@@ -174,7 +208,11 @@ class AlsEngine:
         # launch would leave most of the 3000 resident waves of the row kernels idle in the last round.
         want = {s: max(1, int(chunks)) for s in self.n}
         if auto_chunks:
-            want = {s: max(1, min(want[s], self.rpr[s] // MIN_CHUNK_ROWS)) for s in self.n}
+            # a side updated in reduce mode is accumulated over ALL its rows on every rank: W times the rows per chunk
+            want = {s: max(1, min(want[s], (self.rpr[s] * (W if self.reduce[s] else 1)) // MIN_CHUNK_ROWS)) for s in self.n}
+            for s in self.n:                         # nobody gathers a side whose only consumer runs in reduce mode:
+                if self.reduce["items" if s == "users" else "users"]:      # chunking it would only cost launches
+                    want[s] = 1
         self.chunk_len = {s: max(1, (self.rpr[s] + want[s] - 1) // want[s]) for s in self.n}
         self.chunk_bounds = {s: [(lo, min(self.chunk_len[s], self.rpr[s] - lo))
                                  for lo in range(0, max(self.rpr[s], 1), self.chunk_len[s]) if lo < self.rpr[s]]
@@ -197,6 +235,11 @@ class AlsEngine:
         self.ws = torch.empty(self.K.gram_workspace_bytes(self.f), dtype=torch.uint8, device=dev)
         self.eval_ws = torch.empty(self.K.eval_workspace_bytes(), dtype=torch.uint8, device=dev)
         self.eval_out = z(3, dtype=torch.float64)
+        self.csr_red = {}      # reduce mode: the side's matrix over ALL its rows x this rank's rows of the fixed side
+        self.partial_all = {s: (torch.empty(W * self.rpr[s], pr, dtype=f32, device=dev) if self.reduce[s] else None) for s in self.n}
+        self.partial_mine = {s: (torch.empty(self.rpr[s], pr, dtype=f32, device=dev) if self.reduce[s] else None) for s in self.n}
+        self.scratch_rows = torch.zeros(max(self.rpr.values()), dtype=torch.int32, device=dev)
+        self._stale = {s: False for s in self.n}                              # X[s] not gathered since the last update
         self.csr = {}          # "users": shard with local user rows, "items": shard with local item rows
         self.csr_chunks = {}   # the same rows as one Csr (own row plan) per chunk
         self.has_factors = {"users": False, "items": False}
@@ -232,6 +275,21 @@ class AlsEngine:
                         full.values[edges[c]: edges[c + 1]], full.n_cols, self.f)
                     for c, (lo, ln) in enumerate(bounds)]
 
+        for side, (r_, c_) in (("users", (rows, cols)), ("items", (cols, rows))):
+            if self.reduce[side]:
+                self.csr_red[side] = self._shard_reduce(side, r_, c_, vals)
+
+    def _shard_reduce(self, side, rows, cols, vals):
+        """Reduce mode: every row of ``side`` (at its gathered position) x this rank's rows of the other side
+        (local indices).  Returns (indptr, degrees int32, indices int32, values, w_eff workspace)."""
+        W, r = self.world, self.rank
+        mine = (cols % W) == r
+        rows, cols, vals = rows[mine], cols[mine], vals[mine]
+        indptr, idx, v = coo_to_csr(self.positions(side, rows), cols // W, vals, W * self.rpr[side])
+        deg = (indptr[1:] - indptr[:-1]).to(torch.int32).contiguous()
+        w_eff = torch.empty_like(v) if self.bias else None
+        return indptr.contiguous(), deg, idx.contiguous(), v.contiguous(), w_eff
+
     def _shard(self, side, rows, cols, vals):
         W, r = self.world, self.rank
         other = self._other(side)
@@ -255,20 +313,31 @@ class AlsEngine:
 
     def get_factors(self, side):
         """Full [n, f] factor matrix on the host, in id order."""
-        self._wait(side)
+        self._ensure_gathered(side)
         ids = torch.arange(self.n[side], device=self.device)
         return self.X[side][self.positions(side, ids)][:, : self.f].cpu().numpy()
 
     # ---------------------------------------------------------------- exchange
-    def _publish(self, side, c):
+    def _publish(self, side, c, force=False):
         """Start the all-gather of chunk ``c`` of this rank's freshly written block.  It is ordered after the
         kernels already enqueued on the current stream and runs beside whatever is enqueued next."""
         if self.world == 1:
+            return
+        if self.reduce[self._other(side)] and not force:
+            self._stale[side] = True                 # the other side reads only this rank's block: gather on demand
             return
         lo, ln = self.chunk_bounds[side][c]
         W = self.world
         self._pending[side].append(torch.distributed.all_gather_into_tensor(
             self.X[side][W * lo: W * (lo + ln)], self.factors[side][lo: lo + ln], group=self.group, async_op=True))
+
+    def _ensure_gathered(self, side):
+        """X[side] complete on this rank (reduce mode leaves it un-gathered until somebody needs it)."""
+        if self._stale[side]:
+            self._stale[side] = False
+            for c in range(len(self.chunk_bounds[side])):
+                self._publish(side, c, force=True)
+        self._wait(side)
 
     def _wait(self, side):
         """Make the current stream wait for every all-gather of ``side`` still in flight."""
@@ -293,6 +362,8 @@ class AlsEngine:
             return
         # whiten chunk by chunk, each as soon as ITS all-gather has landed: the passes over the early chunks run while
         # the later chunks are still on the wire (in-flight gathers complete in issue order)
+        if self._stale[fixed]:
+            self._ensure_gathered(fixed)                             # it was last updated while nobody needed all of it
         pending, self._pending[fixed] = self._pending[fixed], []
         done = len(self.chunk_bounds[fixed]) - len(pending)          # chunks whose gather was waited for earlier
         W = self.world
@@ -319,8 +390,52 @@ class AlsEngine:
 
     def half_step(self, side):
         """``side`` <- recompute_factors(other side, C or C^T, gamma)."""
+        if self.reduce[side]:
+            return self._half_step_reduce(side)
         self.prepare(self._other(side))
         self.update(side)
+
+    def _half_step_reduce(self, side):
+        """Reduce mode (module docstring): the fixed side stays where it is; the rows' partial systems travel."""
+        K, W = self.K, self.world
+        fixed = self._other(side)
+        blk = self.factors[fixed]
+        K.gram(blk, self.n_local[fixed], self.f, self.ld, self.bias, self.G, self.ws)
+        torch.distributed.all_reduce(self.G, group=self.group)
+        K.factorize(self.G, self.f, self.ld, self.gamma, self.W_white, self.W_unwhite, self.info, self.ws)
+        v_loc, b_loc = self.V[fixed][: self.rpr[fixed]], self.bias_vec[fixed][: self.rpr[fixed]]     # this rank's block only
+        K.row_transform(blk, self.n_local[fixed], self.f, self.ld, self.W_white, self.bias, v_loc, b_loc if self.bias else None)
+        indptr, deg, idx, vals, w_eff = self.csr_red[side]
+        self._wait(side)
+        works = []
+        for c, (lo, ln) in enumerate(self.chunk_bounds[side]):
+            r0, r1 = W * lo, W * (lo + ln)
+            part = self.partial_all[side][r0:r1]
+            if self.bias and c == 0:                 # values - bias[indices] for ALL entries, once per half step
+                K.accumulate_rows(v_loc, b_loc, indptr[r0: r1 + 1], deg[r0:r1], idx, vals, r1 - r0, idx.numel(), self.f, self.ld,
+                                  part, w_eff)
+            else:
+                K.accumulate_rows(v_loc, None, indptr[r0: r1 + 1], deg[r0:r1], idx, w_eff if self.bias else vals, r1 - r0,
+                                  idx.numel(), self.f, self.ld, part, None)
+            works.append(self._reduce_scatter(self.partial_mine[side][lo: lo + ln], part))
+        for w in works:
+            if w is not None:
+                w.wait()
+        K.eliminate_rows(self.partial_mine[side], self.rpr[side], self.f, self.ld, self.g[side], self.fail, self.scratch_rows)
+        K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, False, self.factors[side], None)
+        self.has_factors[side] = True
+        for c in range(len(self.chunk_bounds[side])):
+            self._publish(side, c)
+
+    def _reduce_scatter(self, out, inp):
+        """out = this rank's slice of the sum over ranks of inp (rank-major blocks).  Backends without a
+        reduce-scatter (gloo) get an all-reduce and a copy."""
+        if torch.distributed.get_backend(self.group) == "nccl":
+            return torch.distributed.reduce_scatter_tensor(out, inp, group=self.group, async_op=True)
+        torch.distributed.all_reduce(inp, group=self.group)
+        n = out.shape[0]
+        out.copy_(inp[self.rank * n: (self.rank + 1) * n])
+        return None
 
     def half_step_unweighted(self, side):
         """Closed form of the un-weighted branch, wmf_model.py:85,88:
@@ -356,7 +471,7 @@ class AlsEngine:
     def eval_sums(self, shard):
         """(sum of squared errors, sum of absolute errors, count) over the stored non-zero entries
         of ``shard``; all-reduced over ranks.  base_model.py:163-176."""
-        self._wait("items")
+        self._ensure_gathered("items")
         self.K.eval_sqerr(self.factors["users"], self.X["items"], self.f, self.ld, self.bias, shard.indptr, shard.indices,
                           shard.values, shard.n_rows, self.eval_out, self.eval_ws)
         if self.world > 1:

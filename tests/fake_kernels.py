@@ -66,6 +66,34 @@ class NumpyKernels:
             vu = v[idx, :f]
             out[u, :f] = np.linalg.solve(np.eye(f) + vu.T @ (vu * wu[:, None]), (wu + 1.0) @ vu)
 
+    # ---- reduce mode: per-row partial systems [f*f (A) | f (y)] in float32, summed over ranks by the engine
+    def partial_row_floats(self, f):
+        return f * f + f
+
+    def accumulate_rows(self, V, bias_vec, indptr, degrees, indices, values, n, nnz, f, ld, partial, w_eff):
+        ip = indptr.numpy()
+        idx = indices.numpy()
+        w = values.numpy().astype(np.float64)
+        if bias_vec is not None:
+            w = w - bias_vec.numpy()[idx]
+            w_eff.numpy()[:] = w
+        Vn = V.numpy()[:, :f].astype(np.float64)
+        out = partial.numpy()
+        assert (np.diff(ip) == degrees.numpy()).all()
+        for i in range(n):
+            cols = idx[ip[i]: ip[i + 1]]
+            U, wi = Vn[cols], w[ip[i]: ip[i + 1]]
+            out[i, : f * f] = (U.T @ (U * wi[:, None])).reshape(-1)
+            out[i, f * f:] = (wi + 1.0) @ U
+
+    def eliminate_rows(self, partial, n, f, ld, g, fail, scratch):
+        P = partial.numpy().astype(np.float64)
+        out = g.numpy()
+        out[:n] = 0
+        for i in range(n):
+            A = np.eye(f) + P[i, : f * f].reshape(f, f)
+            out[i, :f] = np.linalg.solve(A, P[i, f * f:])
+
     def spmm_rows(self, V, indptr, indices, values, n, f, ld, g):
         v = V.numpy().astype(np.float64)
         ip, ix, w = indptr.numpy(), indices.numpy(), values.numpy().astype(np.float64)

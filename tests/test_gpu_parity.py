@@ -338,6 +338,47 @@ def test_chunked_solve_is_bit_identical(k, bias):
     np.testing.assert_array_equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("k,bias", [(16, False), (64, False), (64, True), (50, False), (128, True), (128, False)])
+def test_accumulate_then_eliminate_equals_the_row_solve(k, bias):
+    """The reduce-scatter exchange splits the heavy-row kernel at the sum over stored entries: partial systems of
+    row subsets (here: two halves of every row's entries, as two ranks would hold them), added, then eliminated, must
+    give what wmf_solve_rows gives on the whole rows -- for every degree class, including rows without entries."""
+    from recmodel_amd.engine import AlsEngine, _ptr, _stream
+    C = ragged_matrix(700, 300, seed=k + 5 * bias)
+    eng = AlsEngine(700, 300, k, bias, 0.1)
+    ip = torch.from_numpy(C.indptr.astype(np.int64)).cuda()
+    eng.set_interactions(ip, torch.from_numpy(C.indices.astype(np.int64)).cuda(), torch.from_numpy(C.data).cuda())
+    eng.set_factors("items", orc.init_items(300, k, bias))
+    eng.half_step("users")
+    eng.check_numerics()
+    want = eng.g["users"].clone()                                  # whitened solutions of the ordinary path
+    K, f, ld = eng.K, eng.f, eng.ld
+    pr = K.partial_row_floats(f)
+    assert pr > 0
+    full = eng.csr["users"]
+    total = torch.zeros(700, pr, device="cuda")
+    cols = full.indices.to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(700, device="cuda"), full.indptr[1:] - full.indptr[:-1])
+    for half in (0, 1):                                            # entries with even / odd column: two "ranks"
+        m = (cols % 2) == half
+        cnt = torch.bincount(rows[m], minlength=700)
+        ptr = torch.zeros(701, dtype=torch.int64, device="cuda")
+        torch.cumsum(cnt, 0, out=ptr[1:])
+        idx, val = full.indices[m].contiguous(), full.values[m].contiguous()
+        part = torch.full((700, pr), 7.0, device="cuda")
+        w_eff = torch.empty_like(val) if bias else None
+        K.accumulate_rows(eng.V["items"], eng.bias_vec["items"] if bias else None, ptr, cnt.to(torch.int32), idx, val, 700,
+                          idx.numel(), f, ld, part, w_eff)
+        total += part
+    g2 = torch.zeros(700, ld, device="cuda")
+    fail = torch.zeros(4, dtype=torch.int32, device="cuda")
+    K.eliminate_rows(total, 700, f, ld, g2, fail, torch.zeros(700, dtype=torch.int32, device="cuda"))
+    assert int(fail[0]) == 0
+    a, b = g2.cpu().numpy().astype(np.float64), want.cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert not a[0].any()                                          # the row without entries
+
+
 def test_device_building_blocks_individually():
     """gram / factorize / row_transform against NumPy, including a non-positive-definite Gramian."""
     from recmodel_amd import _lib

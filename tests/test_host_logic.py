@@ -118,3 +118,26 @@ def test_default_chunking_leaves_small_sides_whole():
     e = engine.AlsEngine(5 * engine.MIN_CHUNK_ROWS, 1000, 4, False, 0.1, device="cpu", kernels=NumpyKernels(), chunks=3)
     assert len(e.chunk_bounds["users"]) == 3 and len(e.chunk_bounds["items"]) == 3
     assert sum(n for _, n in e.chunk_bounds["items"]) == 1000
+
+
+def test_reduce_mode_is_chosen_from_the_bytes_per_link(monkeypatch):
+    """engine.AlsEngine picks the exchange per updated side: reduce-scatter of partial systems when
+    rows_per_rank x partial_row_floats is below REDUCE_GAIN x (rows_per_rank of the fixed side) x ld, all-gather otherwise.
+    cfg2 under weak scaling over users: 8 ranks -> items in reduce mode (and the user block neither chunked nor gathered),
+    2 and 4 ranks -> all-gather."""
+    import torch.distributed as dist
+    from fake_kernels import NumpyKernels
+    from recmodel_amd import engine
+
+    class K64(NumpyKernels):
+        def partial_row_floats(self, f):
+            return 2816 if f == 64 else super().partial_row_floats(f)      # what libwmf_hip reports for f = 64
+
+    for world, want in ((2, False), (4, False), (8, True)):
+        monkeypatch.setattr(dist, "is_initialized", lambda: True)
+        monkeypatch.setattr(dist, "get_world_size", lambda group=None, w=world: w)
+        monkeypatch.setattr(dist, "get_rank", lambda group=None: 1)
+        e = engine.AlsEngine(1_000_000 * world, 100_000, 64, False, 0.1, device="meta", kernels=K64())
+        assert e.reduce == {"users": False, "items": want}, (world, e.reduce)
+        assert len(e.chunk_bounds["users"]) == (1 if want else 4)
+        assert len(e.chunk_bounds["items"]) == (3 if want else 1)
