@@ -275,7 +275,8 @@ def main():
                                f"{'reduce-scatter of partial systems' if eng.reduce['users'] else 'all-gather'} in "
                                f"{len(eng.chunk_bounds['users'])} chunk(s), items: "
                                f"{'reduce-scatter of partial systems' if eng.reduce['items'] else 'all-gather'} in "
-                               f"{len(eng.chunk_bounds['items'])} chunk(s)"},
+                               f"{len(eng.chunk_bounds['items'])} chunk(s); accumulation pipelined over arriving chunks: "
+                               f"{[s_ for s_ in ('users', 'items') if eng.pipe[s_]] or 'no'}"},
         "nnz_per_s": 2.0 * nnz * args.steps / elapsed,
         "epoch_algorithmic_GBps": epoch_bytes * args.steps / elapsed / 1e9,
         "epoch_hbm_frac": epoch_bytes * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),

@@ -159,18 +159,20 @@ int wmf_confidence_transform(float* values, int64_t nnz, double alpha, double be
  * summed over ranks (reduce-scatter), and each rank eliminates the rows it owns.  Same arithmetic as
  * wmf_solve_rows' heavy-row kernel (wmf_model.py:233-239), split at the sum over stored entries.
  *   wmf_partial_row_floats(f)  floats per row of a partial-system buffer (0: width not supported);
- *   wmf_accumulate_rows        partial[i] = system of CSR row i over this rank's entries (zeros for an empty row);
- *                              degrees = int32[n] device, indptr[i + 1] - indptr[i]; bias_fixed != NULL needs
- *                              w_eff_workspace (float[nnz], device) for values - bias_fixed[indices];
- *   wmf_eliminate_rows         g[i] = (I + A_i)^-1 y_i from the SUMMED buffer; a row whose system is not positive
- *                              definite is counted in fail_count (there is no CSR here to hand to the pivoted
- *                              fallback); scratch = int32[n] device. */
+ *   wmf_accumulate_rows        slot (i * slot_stride + slot_offset) of `partial` = system of CSR row i over the
+ *                              entries given (zeros for an empty row).  slot_stride = 1, slot_offset = 0: one slot per
+ *                              row.  Larger strides let several calls -- one per arriving chunk of the fixed side --
+ *                              fill different slots of the same rows.  degrees = int32[n] device,
+ *                              indptr[i + 1] - indptr[i]; bias_fixed != NULL needs w_eff_workspace (float[nnz], device);
+ *   wmf_eliminate_rows         g[i] = (I + sum of row i's slots_per_row consecutive slots)^-1 (sum of their y), slots
+ *                              added in order; a row whose system is not positive definite is counted in fail_count
+ *                              (there is no CSR here to hand to the pivoted fallback); scratch = int32[n] device. */
 int64_t wmf_partial_row_floats(int f);
 int wmf_accumulate_rows(const float* V, const float* bias_fixed, const int64_t* indptr, const int32_t* degrees,
                         const int32_t* indices, const float* values, int64_t n, int64_t nnz, int f, int ld,
-                        float* partial, float* w_eff_workspace, void* stream);
-int wmf_eliminate_rows(float* partial, int64_t n, int f, int ld, float* g, int32_t* fail_count, int32_t* scratch,
-                       void* stream);
+                        float* partial, int32_t slot_stride, int32_t slot_offset, float* w_eff_workspace, void* stream);
+int wmf_eliminate_rows(float* partial, int64_t n, int32_t slots_per_row, int f, int ld, float* g, int32_t* fail_count,
+                       int32_t* scratch, void* stream);
 
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------------- */
 /* When enabled, every kernel launch of the device-level entry points is bracketed by HIP events

@@ -39,8 +39,8 @@ SIGNATURES = {
     "wmf_eval_sqerr": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "wmf_predict_pairs": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "wmf_partial_row_floats": (c_i64, [c_int]),
-    "wmf_accumulate_rows": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
-    "wmf_eliminate_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "wmf_accumulate_rows": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
+    "wmf_eliminate_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "wmf_rank_workspace_bytes": (c_i64, [c_i64]),
     "wmf_rank_topn": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wmf_hit_counts": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),

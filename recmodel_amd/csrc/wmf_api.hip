@@ -273,18 +273,20 @@ int64_t wmf_partial_row_floats(int f) { return wmf_directw_partial_floats(f); }
 
 int wmf_accumulate_rows(const float* V, const float* bias_fixed, const int64_t* indptr, const int32_t* degrees,
                         const int32_t* indices, const float* values, int64_t n, int64_t nnz, int f, int ld, float* partial,
-                        float* w_eff_workspace, void* stream) {
+                        int32_t slot_stride, int32_t slot_offset, float* w_eff_workspace, void* stream) {
     int rc = check_shape(f, ld);
     if (rc) return rc;
-    if (!V || !indptr || !degrees || !partial || n < 0 || nnz < 0 || (nnz > 0 && (!indices || !values))) {
-        wmf_set_error("wmf_accumulate_rows: null pointer or negative size"); return WMF_EINVAL;
+    if (!V || !indptr || !degrees || !partial || n < 0 || nnz < 0 || (nnz > 0 && (!indices || !values)) || slot_stride < 1 ||
+        slot_offset < 0 || slot_offset >= slot_stride) {
+        wmf_set_error("wmf_accumulate_rows: null pointer, negative size or bad slot"); return WMF_EINVAL;
     }
     const int64_t pr = wmf_directw_partial_floats(f);
     if (pr == 0) { wmf_set_error("wmf_accumulate_rows: f=%d not supported (f <= 144)", f); return WMF_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return WMF_OK;
-    if (nnz == 0) {                                               // nothing stored on this rank: every partial system is zero
-        if (hipMemsetAsync(partial, 0, (size_t)n * pr * sizeof(float), st) != hipSuccess) { wmf_set_error("wmf_accumulate_rows: memset failed"); return WMF_EHIP; }
+    if (nnz == 0) {                                               // nothing stored here: every partial system of this slot is zero
+        if (hipMemset2DAsync(partial + (size_t)slot_offset * pr, (size_t)slot_stride * pr * sizeof(float), 0, (size_t)pr * sizeof(float),
+                             (size_t)n, st) != hipSuccess) { wmf_set_error("wmf_accumulate_rows: memset failed"); return WMF_EHIP; }
         return WMF_OK;
     }
     if (bias_fixed) {
@@ -294,20 +296,21 @@ int wmf_accumulate_rows(const float* V, const float* bias_fixed, const int64_t* 
     }
     {
         WmfProfScope ps(WMF_SLOT_SOLVE_DIRECT, st);
-        if (wmf_launch_accumulate(V, indptr, degrees, indices, values, n, f, ld, partial, st)) { wmf_set_error("wmf_accumulate_rows: no kernel for f=%d", f); return WMF_EINVAL; }
+        if (wmf_launch_accumulate(V, indptr, degrees, indices, values, n, f, ld, partial, slot_stride, slot_offset, st)) { wmf_set_error("wmf_accumulate_rows: no kernel for f=%d", f); return WMF_EINVAL; }
     }
     return check_launch("wmf_accumulate_rows");
 }
 
-int wmf_eliminate_rows(float* partial, int64_t n, int f, int ld, float* g, int32_t* fail_count, int32_t* scratch, void* stream) {
+int wmf_eliminate_rows(float* partial, int64_t n, int32_t slots_per_row, int f, int ld, float* g, int32_t* fail_count,
+                       int32_t* scratch, void* stream) {
     int rc = check_shape(f, ld);
     if (rc) return rc;
-    if (!partial || !g || !fail_count || !scratch || n < 0) { wmf_set_error("wmf_eliminate_rows: null pointer or negative size"); return WMF_EINVAL; }
+    if (!partial || !g || !fail_count || !scratch || n < 0 || slots_per_row < 1) { wmf_set_error("wmf_eliminate_rows: null pointer or bad size"); return WMF_EINVAL; }
     if (wmf_directw_partial_floats(f) == 0) { wmf_set_error("wmf_eliminate_rows: f=%d not supported (f <= 144)", f); return WMF_EINVAL; }
     if (n == 0) return WMF_OK;
     {
         WmfProfScope ps(WMF_SLOT_SOLVE_HEAVY, (hipStream_t)stream);
-        if (wmf_launch_eliminate(partial, n, f, ld, g, scratch, fail_count, (hipStream_t)stream)) { wmf_set_error("wmf_eliminate_rows: no kernel for f=%d", f); return WMF_EINVAL; }
+        if (wmf_launch_eliminate(partial, n, slots_per_row, f, ld, g, scratch, fail_count, (hipStream_t)stream)) { wmf_set_error("wmf_eliminate_rows: no kernel for f=%d", f); return WMF_EINVAL; }
     }
     return check_launch("wmf_eliminate_rows");
 }

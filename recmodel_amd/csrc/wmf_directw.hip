@@ -84,7 +84,8 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                                                               float* __restrict__ g, int32_t* __restrict__ fb_rows,
                                                               int32_t* __restrict__ fb_count, int dbg,
                                                               const int64_t* __restrict__ seg_lo, const int32_t* __restrict__ seg_d,
-                                                              const int32_t* __restrict__ seg_first, float* __restrict__ partial) {
+                                                              const int32_t* __restrict__ seg_first, float* __restrict__ partial,
+                                                              int slot_a, int slot_b) {
     constexpr int NT = NFB * (NFB + 1) / 2;
     constexpr int GS = DwCfg<NFB>::GS;                           // MFMA k-steps (4 entries each) per pipelined group
     __shared__ __attribute__((aligned(16))) float Pan1[NFB * 320];           // original tiles of block row p
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
         // racc[fb] = this lane's share (its q) of y[16 fb + r]; the four shares are added when block fb becomes the pivot
         if (itn < count) prime(lon, dn);                         // next row's first loads fly during the elimination
         if constexpr (MODE == 1) {                               // partial tiles of this segment: [tile][reg][lane]
-            float* out = partial + it * (int64_t)WMF_DW_PARTIAL(NFB, BORDER);
+            float* out = partial + (it * slot_a + slot_b) * (int64_t)WMF_DW_PARTIAL(NFB, BORDER);   // slot of work item `it`
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -200,8 +201,9 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
             continue;
         }
         if constexpr (MODE == 2) {                               // sum the segments of heavy row `it` in a fixed order
-            const int sg0 = seg_first ? seg_first[it] : (int)it, sg1 = seg_first ? seg_first[it + 1] : (int)it + 1;
-            for (int sgm = sg0; sgm < sg1; ++sgm) {
+            // seg_first == NULL: row `it` owns the slot_a consecutive slots it * slot_a ..
+            const int64_t sg0 = seg_first ? seg_first[it] : it * slot_a, sg1 = seg_first ? seg_first[it + 1] : sg0 + slot_a;
+            for (int64_t sgm = sg0; sgm < sg1; ++sgm) {
                 const float* in = partial + sgm * (int64_t)WMF_DW_PARTIAL(NFB, BORDER);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
@@ -345,16 +347,16 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
     if (normal > 0)
         hipLaunchKernelGGL((solve_directw_kernel<NFB, 0, BORDER>), dim3((unsigned)(normal < cap ? normal : cap)), dim3(64), 0, st,
                            rows, normal, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
-                           nullptr, nullptr, nullptr, nullptr);
+                           nullptr, nullptr, nullptr, nullptr, 1, 0);
     if (pl->heavy_count > 0) {
         const int64_t nseg = pl->seg_total;
         hipLaunchKernelGGL((solve_directw_kernel<NFB, 1, BORDER>), dim3((unsigned)(nseg < cap ? nseg : cap)), dim3(64), 0, st, rows,
                            nseg, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg, pl->seg_lo,
-                           pl->seg_d, pl->seg_first, pl->partial);
+                           pl->seg_d, pl->seg_first, pl->partial, 1, 0);
         const int64_t nh = pl->heavy_count;
         hipLaunchKernelGGL((solve_directw_kernel<NFB, 2, BORDER>), dim3((unsigned)(nh < cap ? nh : cap)), dim3(64), 0, st,
                            rows + normal, nh, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
-                           pl->seg_lo, pl->seg_d, pl->seg_first, pl->partial);
+                           pl->seg_lo, pl->seg_d, pl->seg_first, pl->partial, 1, 0);
     }
 }
 
@@ -362,19 +364,20 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
 // segment per row, slot = row) and MODE 2 over a buffer of summed partial systems (one slot per row, row = slot).
 template <int NFB, bool BORDER>
 static void launch_accumulate_nfb(const float* V, const int64_t* indptr, const int32_t* degrees, const int32_t* indices,
-                                  const float* vals, int64_t n, int f, int ld, float* partial, hipStream_t st) {
+                                  const float* vals, int64_t n, int f, int ld, float* partial, int slot_stride, int slot_offset,
+                                  hipStream_t st) {
     const int64_t cap = 256 * 4 * DwCfg<NFB>::OCC * 3;
     hipLaunchKernelGGL((solve_directw_kernel<NFB, 1, BORDER>), dim3((unsigned)(n < cap ? n : cap)), dim3(64), 0, st, nullptr, n, V,
                        nullptr, indptr, indices, vals, f, ld, nullptr, nullptr, nullptr, wmf_debug_flags & ~3, indptr, degrees,
-                       nullptr, partial);
+                       nullptr, partial, slot_stride, slot_offset);
 }
 template <int NFB, bool BORDER>
-static void launch_eliminate_nfb(float* partial, int64_t n, int f, int ld, float* g, int32_t* fb_rows, int32_t* fail_count,
-                                 hipStream_t st) {
+static void launch_eliminate_nfb(float* partial, int64_t n, int slots_per_row, int f, int ld, float* g, int32_t* fb_rows,
+                                 int32_t* fail_count, hipStream_t st) {
     const int64_t cap = 256 * 4 * DwCfg<NFB>::OCC * 3;
     hipLaunchKernelGGL((solve_directw_kernel<NFB, 2, BORDER>), dim3((unsigned)(n < cap ? n : cap)), dim3(64), 0, st, nullptr, n,
                        nullptr, nullptr, nullptr, nullptr, nullptr, f, ld, g, fb_rows, fail_count, wmf_debug_flags & ~3, nullptr,
-                       nullptr, nullptr, partial);
+                       nullptr, nullptr, partial, slots_per_row, 0);
 }
 static bool dw_border(int f) { return f > 16 && f % 16 == 1 && (f / 16) % 4 != 3 && !(wmf_debug_flags & 256); }
 
@@ -385,12 +388,13 @@ int64_t wmf_directw_partial_floats(int f) {
 }
 
 int wmf_launch_accumulate(const float* V, const int64_t* indptr, const int32_t* degrees, const int32_t* indices,
-                          const float* vals, int64_t n, int f, int ld, float* partial, hipStream_t st) {
+                          const float* vals, int64_t n, int f, int ld, float* partial, int slot_stride, int slot_offset,
+                          hipStream_t st) {
     if (n <= 0) return 0;
     if (f > 144) return -1;
     if (dw_border(f)) {
         switch (f / 16) {
-#define C_(N) case N: launch_accumulate_nfb<N, true>(V, indptr, degrees, indices, vals, n, f, ld, partial, st); break;
+#define C_(N) case N: launch_accumulate_nfb<N, true>(V, indptr, degrees, indices, vals, n, f, ld, partial, slot_stride, slot_offset, st); break;
             C_(1) C_(2) C_(4) C_(5) C_(6) C_(8)
 #undef C_
             default: return -1;
@@ -398,7 +402,7 @@ int wmf_launch_accumulate(const float* V, const int64_t* indptr, const int32_t* 
         return 0;
     }
     switch ((f + 15) / 16) {
-#define C_(N) case N: launch_accumulate_nfb<N, false>(V, indptr, degrees, indices, vals, n, f, ld, partial, st); break;
+#define C_(N) case N: launch_accumulate_nfb<N, false>(V, indptr, degrees, indices, vals, n, f, ld, partial, slot_stride, slot_offset, st); break;
         C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9)
 #undef C_
         default: return -1;
@@ -406,13 +410,13 @@ int wmf_launch_accumulate(const float* V, const int64_t* indptr, const int32_t* 
     return 0;
 }
 
-int wmf_launch_eliminate(float* partial, int64_t n, int f, int ld, float* g, int32_t* fb_rows, int32_t* fail_count,
-                         hipStream_t st) {
+int wmf_launch_eliminate(float* partial, int64_t n, int slots_per_row, int f, int ld, float* g, int32_t* fb_rows,
+                         int32_t* fail_count, hipStream_t st) {
     if (n <= 0) return 0;
     if (f > 144) return -1;
     if (dw_border(f)) {
         switch (f / 16) {
-#define C_(N) case N: launch_eliminate_nfb<N, true>(partial, n, f, ld, g, fb_rows, fail_count, st); break;
+#define C_(N) case N: launch_eliminate_nfb<N, true>(partial, n, slots_per_row, f, ld, g, fb_rows, fail_count, st); break;
             C_(1) C_(2) C_(4) C_(5) C_(6) C_(8)
 #undef C_
             default: return -1;
@@ -420,7 +424,7 @@ int wmf_launch_eliminate(float* partial, int64_t n, int f, int ld, float* g, int
         return 0;
     }
     switch ((f + 15) / 16) {
-#define C_(N) case N: launch_eliminate_nfb<N, false>(partial, n, f, ld, g, fb_rows, fail_count, st); break;
+#define C_(N) case N: launch_eliminate_nfb<N, false>(partial, n, slots_per_row, f, ld, g, fb_rows, fail_count, st); break;
         C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9)
 #undef C_
         default: return -1;

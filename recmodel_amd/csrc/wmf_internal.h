@@ -51,9 +51,10 @@ int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* biasv, c
                        const int32_t* indices, const float* vals, int f, int ld, float* g, hipStream_t st);
 int64_t wmf_directw_partial_floats(int f);
 int wmf_launch_accumulate(const float* V, const int64_t* indptr, const int32_t* degrees, const int32_t* indices,
-                          const float* vals, int64_t n, int f, int ld, float* partial, hipStream_t st);
-int wmf_launch_eliminate(float* partial, int64_t n, int f, int ld, float* g, int32_t* fb_rows, int32_t* fail_count,
-                         hipStream_t st);
+                          const float* vals, int64_t n, int f, int ld, float* partial, int slot_stride, int slot_offset,
+                          hipStream_t st);
+int wmf_launch_eliminate(float* partial, int64_t n, int slots_per_row, int f, int ld, float* g, int32_t* fb_rows,
+                         int32_t* fail_count, hipStream_t st);
 void wmf_launch_bias_adjust(const float* vals, const int32_t* indices, const float* biasv, int64_t nnz, float* w_eff,
                             hipStream_t st);
 int wmf_launch_direct64(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,

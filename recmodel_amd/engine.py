@@ -32,6 +32,14 @@ exchange of one chunk behind the accumulation of the next -- and each rank elimi
 (wmf_eliminate_rows).  Per link that is rows_per_rank x (f(f+1)/2 + f) floats instead of rows_per_rank_of_the_fixed_side
 x f; the engine picks the mode per side from exactly that comparison (REDUCE_GAIN), and a side whose only consumer runs
 in reduce mode is not gathered at all until somebody asks for it (get_factors).
+
+Pipelined gather mode.  When the fixed side does arrive by all-gather in several chunks and the rows being updated are
+heavy (cfg2's items at 2 and 4 GPUs: hundreds of entries per row and chunk), the update does not wait for the last
+chunk: the gathered matrix is chunk-major, so a row's entries are grouped by chunk; as soon as chunk c has landed and
+been whitened, the rows' partial systems over THAT chunk's entries are accumulated into slot c of a
+[rows, chunks, partial_row_floats] buffer (wmf_accumulate_rows with slot_stride = chunks), and after the last chunk
+wmf_eliminate_rows adds a row's slots in order and solves.  Only the last chunk's accumulation and the elimination
+are left once the transfer ends.
 """
 import ctypes
 import os
@@ -97,12 +105,14 @@ class HipKernels:
     def partial_row_floats(self, f):
         return int(self.lib.wmf_partial_row_floats(f))
 
-    def accumulate_rows(self, V, bias_vec, indptr, degrees, indices, values, n, nnz, f, ld, partial, w_eff):
+    def accumulate_rows(self, V, bias_vec, indptr, degrees, indices, values, n, nnz, f, ld, partial, w_eff, slot_stride=1,
+                        slot_offset=0):
         _lib.check(self.lib.wmf_accumulate_rows(_ptr(V), _ptr(bias_vec), _ptr(indptr), _ptr(degrees), _ptr(indices), _ptr(values),
-                                                n, nnz, f, ld, _ptr(partial), _ptr(w_eff), _stream()))
+                                                n, nnz, f, ld, _ptr(partial), slot_stride, slot_offset, _ptr(w_eff), _stream()))
 
-    def eliminate_rows(self, partial, n, f, ld, g, fail, scratch):
-        _lib.check(self.lib.wmf_eliminate_rows(_ptr(partial), n, f, ld, _ptr(g), _ptr(fail), _ptr(scratch), _stream()))
+    def eliminate_rows(self, partial, n, f, ld, g, fail, scratch, slots_per_row=1):
+        _lib.check(self.lib.wmf_eliminate_rows(_ptr(partial), n, slots_per_row, f, ld, _ptr(g), _ptr(fail), _ptr(scratch),
+                                               _stream()))
 
     def spmm_rows(self, V, indptr, indices, values, n, f, ld, g):
         _lib.check(self.lib.wmf_spmm_rows(_ptr(V), _ptr(indptr), _ptr(indices), _ptr(values), n, f, ld, _ptr(g), _stream()))
@@ -155,6 +165,7 @@ def coo_to_csr(rows, cols, vals, n_rows):
 
 MIN_CHUNK_ROWS = 32768          # default chunking never makes chunks smaller than this
 REDUCE_GAIN = 0.8               # reduce mode when its bytes per link are below this fraction of the all-gather's
+PIPE_MIN_ENTRIES = 48           # pipelined gather mode only when a row has at least this many entries per arriving chunk
 
 
 def gathered_positions(ids, world, rows_per_rank, chunk_len):
@@ -170,7 +181,7 @@ class AlsEngine:
     """Weighted-ALS state of one rank: factor blocks, whitened gathers, CSR shards."""
 
     def __init__(self, n_users, n_items, dim, bias, gamma, device=None, group=None, kernels=None, chunks=None,
-                 reduce_mode=None):
+                 reduce_mode=None, pipe_mode=None):
         self.K = kernels if kernels is not None else HipKernels()     # raises without a GPU / built library
         self.lib = getattr(self.K, "lib", None)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -194,12 +205,15 @@ class AlsEngine:
         for s in self.n:
             o = "items" if s == "users" else "users"
             gain = W > 1 and pr > 0 and self.rpr[s] * pr < REDUCE_GAIN * self.rpr[o] * self.ld
-            self.reduce[s] = W > 1 and pr > 0 and (forced == "1" or (forced is None and gain))
+            # a summed system that is not positive definite cannot be handed to the pivoted fallback (no CSR at the
+            # owner), and only bias-adjusted weights can go negative: with biases the mode has to be asked for
+            self.reduce[s] = W > 1 and pr > 0 and (forced == "1" or (forced is None and gain and not self.bias))
         if self.reduce["users"] and self.reduce["items"]:
             # both at once would leave nobody holding a whole side; keep the one that saves more
             keep = "items" if self.rpr["items"] <= self.rpr["users"] else "users"
             self.reduce = {s: s == keep for s in self.n}
         self.pr = pr
+        self.pipe_mode = pipe_mode
         auto_chunks = chunks is None and "WMF_CHUNKS" not in os.environ
         if chunks is None:
             chunks = int(os.environ.get("WMF_CHUNKS", "4")) if W > 1 else 1
@@ -235,6 +249,9 @@ class AlsEngine:
         self.ws = torch.empty(self.K.gram_workspace_bytes(self.f), dtype=torch.uint8, device=dev)
         self.eval_ws = torch.empty(self.K.eval_workspace_bytes(), dtype=torch.uint8, device=dev)
         self.eval_out = z(3, dtype=torch.float64)
+        self.pipe = {s: False for s in self.n}               # pipelined gather mode, decided in set_interactions (needs the degrees)
+        self.csr_pipe = {}     # per chunk of the fixed side: (indptr, degrees, indices, values, w_eff) over this rank's rows
+        self.partial_pipe = {}
         self.csr_red = {}      # reduce mode: the side's matrix over ALL its rows x this rank's rows of the fixed side
         self.partial_all = {s: (torch.empty(W * self.rpr[s], pr, dtype=f32, device=dev) if self.reduce[s] else None) for s in self.n}
         self.partial_mine = {s: (torch.empty(self.rpr[s], pr, dtype=f32, device=dev) if self.reduce[s] else None) for s in self.n}
@@ -278,6 +295,34 @@ class AlsEngine:
         for side, (r_, c_) in (("users", (rows, cols)), ("items", (cols, rows))):
             if self.reduce[side]:
                 self.csr_red[side] = self._shard_reduce(side, r_, c_, vals)
+            else:
+                self._setup_pipe(side)
+
+    def _setup_pipe(self, side):
+        """Pipelined gather mode for ``side`` (module docstring) if its rows are heavy enough per arriving chunk."""
+        fixed = self._other(side)
+        bounds = self.chunk_bounds[fixed]
+        full = self.csr[side]
+        forced = os.environ.get("WMF_PIPE") if self.pipe_mode is None else ("1" if self.pipe_mode else "0")
+        heavy = full.nnz >= PIPE_MIN_ENTRIES * max(1, self.n_local[side]) * len(bounds)
+        self.pipe[side] = (self.world > 1 and len(bounds) > 1 and self.pr > 0 and not self.reduce[fixed]
+                           and (forced == "1" or (forced is None and heavy and not self.bias)))
+        if not self.pipe[side]:
+            return
+        W, n = self.world, self.rpr[side]
+        idx = full.indices.to(torch.int64)
+        rows = torch.repeat_interleave(torch.arange(n, device=self.device), full.indptr[1:] - full.indptr[:-1])
+        subs = []
+        for lo, ln in bounds:
+            m = (idx >= W * lo) & (idx < W * (lo + ln))
+            cnt = torch.bincount(rows[m], minlength=n)
+            ptr = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+            torch.cumsum(cnt, 0, out=ptr[1:])
+            v = full.values[m].contiguous()
+            subs.append((ptr, cnt.to(torch.int32).contiguous(), full.indices[m].contiguous(), v,
+                         torch.empty_like(v) if self.bias else None))
+        self.csr_pipe[side] = subs
+        self.partial_pipe[side] = torch.empty(n * len(bounds), self.pr, dtype=torch.float32, device=self.device)
 
     def _shard_reduce(self, side, rows, cols, vals):
         """Reduce mode: every row of ``side`` (at its gathered position) x this rank's rows of the other side
@@ -392,8 +437,39 @@ class AlsEngine:
         """``side`` <- recompute_factors(other side, C or C^T, gamma)."""
         if self.reduce[side]:
             return self._half_step_reduce(side)
+        if self.pipe[side]:
+            return self._half_step_pipelined(side)
         self.prepare(self._other(side))
         self.update(side)
+
+    def _half_step_pipelined(self, side):
+        """Pipelined gather mode (module docstring): accumulate over each chunk of the fixed side as it lands."""
+        K, W = self.K, self.world
+        fixed = self._other(side)
+        K.gram(self.factors[fixed], self.n_local[fixed], self.f, self.ld, self.bias, self.G, self.ws)
+        torch.distributed.all_reduce(self.G, group=self.group)
+        K.factorize(self.G, self.f, self.ld, self.gamma, self.W_white, self.W_unwhite, self.info, self.ws)
+        if self._stale[fixed]:
+            self._ensure_gathered(fixed)
+        pending, self._pending[fixed] = self._pending[fixed], []
+        bounds = self.chunk_bounds[fixed]
+        done = len(bounds) - len(pending)
+        V, bvec = self.V[fixed], self.bias_vec[fixed]
+        self._wait(side)
+        n, C = self.rpr[side], len(bounds)
+        for c, ((lo, ln), (ptr, deg, idx, val, w_eff)) in enumerate(zip(bounds, self.csr_pipe[side])):
+            if c >= done:
+                pending[c - done].wait()
+            rows = slice(W * lo, W * (lo + ln))
+            K.row_transform(self.X[fixed][rows], W * ln, self.f, self.ld, self.W_white, self.bias, V[rows],
+                            bvec[rows] if self.bias else None)
+            K.accumulate_rows(V, bvec if self.bias else None, ptr, deg, idx, val, n, idx.numel(), self.f, self.ld,
+                              self.partial_pipe[side], w_eff, slot_stride=C, slot_offset=c)
+        K.eliminate_rows(self.partial_pipe[side], n, self.f, self.ld, self.g[side], self.fail, self.scratch_rows, slots_per_row=C)
+        K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, False, self.factors[side], None)
+        self.has_factors[side] = True
+        for c in range(len(self.chunk_bounds[side])):
+            self._publish(side, c)
 
     def _half_step_reduce(self, side):
         """Reduce mode (module docstring): the fixed side stays where it is; the rows' partial systems travel."""

@@ -70,7 +70,8 @@ class NumpyKernels:
     def partial_row_floats(self, f):
         return f * f + f
 
-    def accumulate_rows(self, V, bias_vec, indptr, degrees, indices, values, n, nnz, f, ld, partial, w_eff):
+    def accumulate_rows(self, V, bias_vec, indptr, degrees, indices, values, n, nnz, f, ld, partial, w_eff, slot_stride=1,
+                        slot_offset=0):
         ip = indptr.numpy()
         idx = indices.numpy()
         w = values.numpy().astype(np.float64)
@@ -78,7 +79,7 @@ class NumpyKernels:
             w = w - bias_vec.numpy()[idx]
             w_eff.numpy()[:] = w
         Vn = V.numpy()[:, :f].astype(np.float64)
-        out = partial.numpy()
+        out = partial.numpy().reshape(-1, f * f + f)[slot_offset::slot_stride]
         assert (np.diff(ip) == degrees.numpy()).all()
         for i in range(n):
             cols = idx[ip[i]: ip[i + 1]]
@@ -86,8 +87,8 @@ class NumpyKernels:
             out[i, : f * f] = (U.T @ (U * wi[:, None])).reshape(-1)
             out[i, f * f:] = (wi + 1.0) @ U
 
-    def eliminate_rows(self, partial, n, f, ld, g, fail, scratch):
-        P = partial.numpy().astype(np.float64)
+    def eliminate_rows(self, partial, n, f, ld, g, fail, scratch, slots_per_row=1):
+        P = partial.numpy().astype(np.float64).reshape(-1, slots_per_row, f * f + f)[:n].sum(axis=1)
         out = g.numpy()
         out[:n] = 0
         for i in range(n):

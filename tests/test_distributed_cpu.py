@@ -23,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, bias, out_path, reduce_mode=None):
+def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -36,12 +36,14 @@ def _worker(rank, world, port, bias, out_path, reduce_mode=None):
         n_users, n_items, dim = 203, 57, 6           # not multiples of the world size: padding rows exist
         indptr, indices, counts = synth.make_counts(n_users, n_items, 5, seed=11)
         values = (10 * torch.log(1 + counts)).to(torch.float32)
-        eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cpu", kernels=NumpyKernels(), chunks=4, reduce_mode=reduce_mode)
+        eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cpu", kernels=NumpyKernels(), chunks=4, reduce_mode=reduce_mode, pipe_mode=pipe_mode)
         if reduce_mode:
             assert eng.reduce == {"users": False, "items": True}             # the smaller side travels as partial systems
         assert len(eng.csr_chunks) == 0 and len(eng.chunk_bounds["users"]) == 4
         assert eng.world == world and eng.rank == rank
         eng.set_interactions(indptr, indices, values)
+        if pipe_mode:
+            assert eng.pipe == {"users": True, "items": True} and len(eng.csr_pipe["items"]) == 4
         # every stored entry lands on exactly one rank, in both orientations
         for side in ("users", "items"):
             t = torch.tensor([eng.csr[side].nnz], dtype=torch.int64)
@@ -61,14 +63,16 @@ def _worker(rank, world, port, bias, out_path, reduce_mode=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bias,reduce_mode", [(False, None), (True, None), (False, True), (True, True)])
-def test_two_rank_als_matches_single_process_oracle(tmp_path, bias, reduce_mode):
+@pytest.mark.parametrize("bias,reduce_mode,pipe_mode", [(False, None, None), (True, None, None), (False, True, None),
+                                                        (True, True, None), (False, False, True), (True, False, True)])
+def test_two_rank_als_matches_single_process_oracle(tmp_path, bias, reduce_mode, pipe_mode):
     """reduce_mode=True: the item half step accumulates partial systems on every rank and reduce-scatters them
-    (here an all-reduce + slice: gloo has no reduce-scatter); the user block is then only gathered on demand."""
+    (here an all-reduce + slice: gloo has no reduce-scatter); the user block is then only gathered on demand.
+    pipe_mode=True: both half steps accumulate over each gathered chunk of the fixed side as it arrives."""
     from oracle import wmf_oracle as orc
     from recmodel_amd import synth
     out = str(tmp_path / "out.npz")
-    mp.spawn(_worker, args=(2, _free_port(), bias, out, reduce_mode), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), bias, out, reduce_mode, pipe_mode), nprocs=2, join=True)
     got = np.load(out)
     n_users, n_items, dim = 203, 57, 6
     indptr, indices, counts = synth.make_counts(n_users, n_items, 5, seed=11)

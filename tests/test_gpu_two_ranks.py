@@ -23,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, bias, out_path, reduce_mode=None):
+def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
@@ -35,9 +35,11 @@ def _worker(rank, world, port, bias, out_path, reduce_mode=None):
         n_users, n_items, dim = 1203, 257, 24
         indptr, indices, counts = synth.make_counts(n_users, n_items, 9, seed=11)
         values = (10 * torch.log(1 + counts)).to(torch.float32)
-        eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cuda:0", chunks=3, reduce_mode=reduce_mode)
+        eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cuda:0", chunks=3, reduce_mode=reduce_mode, pipe_mode=pipe_mode)
         assert eng.reduce["items"] == bool(reduce_mode)
+        eng_pipe_expected = bool(pipe_mode)
         eng.set_interactions(indptr, indices, values)
+        assert eng.pipe["items"] == eng_pipe_expected and eng.pipe["users"] == eng_pipe_expected
         eng.set_factors("items", orc.init_items(n_items, dim, bias))
         for _ in range(2):
             eng.half_step("users")
@@ -52,13 +54,14 @@ def _worker(rank, world, port, bias, out_path, reduce_mode=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bias,reduce_mode", [(False, None), (True, None), (False, True), (True, True)])
-def test_two_ranks_one_gpu_match_oracle(tmp_path, bias, reduce_mode):
+@pytest.mark.parametrize("bias,reduce_mode,pipe_mode", [(False, None, None), (True, None, None), (False, True, None),
+                                                        (True, True, None), (False, False, True), (True, False, True)])
+def test_two_ranks_one_gpu_match_oracle(tmp_path, bias, reduce_mode, pipe_mode):
     from oracle import wmf_oracle as orc
     from recmodel_amd import synth
     out = str(tmp_path / "out.npz")
     try:
-        mp.spawn(_worker, args=(2, _free_port(), bias, out, reduce_mode), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), bias, out, reduce_mode, pipe_mode), nprocs=2, join=True)
     except Exception as exc:                      # gloo without device-tensor collectives on this build
         if "gloo" in str(exc).lower() and "cuda" in str(exc).lower():
             pytest.skip(f"gloo cannot move device tensors here: {exc}")
