@@ -92,6 +92,28 @@ def test_two_rank_als_matches_single_process_oracle(tmp_path, bias, reduce_mode,
     assert got["sums"][2] == raw.nnz
 
 
+@pytest.mark.parametrize("mode", ["gather", "reduce", "pipe"])
+def test_three_ranks_all_modes(tmp_path, mode):
+    """An odd world size (padding rows on two of the three ranks, uneven last chunk) through each exchange mode."""
+    from oracle import wmf_oracle as orc
+    from recmodel_amd import synth
+    out = str(tmp_path / "out.npz")
+    kw = {"gather": (False, False), "reduce": (True, None), "pipe": (False, True)}[mode]
+    mp.spawn(_worker, args=(3, _free_port(), False, out, kw[0], kw[1]), nprocs=3, join=True)
+    got = np.load(out)
+    n_users, n_items, dim = 203, 57, 6
+    indptr, indices, counts = synth.make_counts(n_users, n_items, 5, seed=11)
+    C = synth.to_scipy(indptr, indices, counts, (n_users, n_items)).astype(np.float64)
+    C.data = 10 * np.log(1 + C.data)
+    CT = C.T.tocsr()
+    items = orc.init_items(n_items, dim, False)
+    for _ in range(2):
+        users = orc.recompute_factors(items, C, 0.1)
+        items = orc.recompute_factors(users, CT, 0.1)
+    np.testing.assert_allclose(got["users"], users, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(got["items"], items, rtol=2e-4, atol=2e-5)
+
+
 def test_single_rank_engine_with_stand_in_matches_oracle():
     """world = 1 through the same code path (no process group)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
