@@ -82,3 +82,53 @@ def test_two_ranks_one_gpu_match_oracle(tmp_path, bias, reduce_mode, pipe_mode):
     assert np.linalg.norm(got["items"] - items) <= 1e-3 * np.linalg.norm(items)
     mse = orc.eval_prec(users, items, raw, bias)
     assert abs(got["sums"][0] / got["sums"][2] - mse) <= 1e-4 * mse
+
+
+def _tiny_worker(rank, world, port, mode, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import wmf_oracle as orc
+        from recmodel_amd.engine import AlsEngine
+        import scipy.sparse as sp
+        C = _tiny_matrix()
+        eng = AlsEngine(C.shape[0], C.shape[1], 5, False, 0.1, device="cuda:0", chunks=2,
+                        reduce_mode=(mode == "reduce"), pipe_mode=(mode == "pipe"))
+        eng.set_interactions(torch.from_numpy(C.indptr.astype(np.int64)), torch.from_numpy(C.indices.astype(np.int64)),
+                             torch.from_numpy(C.data.astype(np.float32)))
+        eng.set_factors("items", orc.init_items(C.shape[1], 5))
+        eng.half_step("users")
+        eng.half_step("items")
+        eng.check_numerics()
+        users, items = eng.get_factors("users"), eng.get_factors("items")
+        if rank == 0:
+            np.savez(out_path, users=users, items=items)
+    finally:
+        dist.destroy_process_group()
+
+
+def _tiny_matrix():
+    """3 users x 40 items; user 1 (the only user of rank 1) bought nothing: rank 1 holds no entries at all, and
+    half of the items have no entries either."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(2)
+    rows = np.repeat([0, 2], 12)
+    cols = np.concatenate([rng.choice(20, 12, replace=False), rng.choice(20, 12, replace=False)])
+    return sp.csr_matrix((rng.integers(1, 6, 24).astype(np.float64), (rows, cols)), shape=(3, 40))
+
+
+@pytest.mark.parametrize("mode", ["gather", "reduce", "pipe"])
+def test_rank_without_entries(tmp_path, mode):
+    from oracle import wmf_oracle as orc
+    out = str(tmp_path / "tiny.npz")
+    mp.spawn(_tiny_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
+    got = np.load(out)
+    C = _tiny_matrix()
+    items0 = orc.init_items(40, 5)
+    users = orc.recompute_factors(items0, C, 0.1)
+    items = orc.recompute_factors(users, C.T.tocsr(), 0.1)
+    assert np.linalg.norm(got["users"] - users) <= 1e-4 * np.linalg.norm(users)
+    assert np.linalg.norm(got["items"] - items) <= 1e-4 * np.linalg.norm(items)
+    assert not got["users"][1].any() and not got["items"][20:].any()
