@@ -14,7 +14,8 @@
 //              layout of the Gauss-Jordan sweep of wmf_solve.hip, so it is inverted in place with 16
 //              v_fmac_dpp steps, and the result is already the MFMA A operand;
 //        W_pj = X B_pj  : four MFMAs with the tile's own registers as the B operand (k = 4q + reg);
-//        B_ij -= B_pi^T W_pj : both operands from a two-panel LDS buffer (originals and W), in place;
+//        B_ij -= B_pi^T W_pj : both operands are registers the lane already holds (element e of the original tile
+//              (p,i) and of W_pj in accumulator layout are exactly what MFMA step e wants) -- no LDS panels;
 //        w_p  = X y_p (DPP row sums), y_i -= B_pi^T w_p with the A operands the MFMAs just loaded.
 //   D. g_p = w_p - sum_{j>p} W_pj g_j with DPP row sums; no triangular solves are left.
 // A non-positive pivot (system not positive definite: possible with biases) bounces the row to the
@@ -88,8 +89,6 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                                                               int slot_a, int slot_b) {
     constexpr int NT = NFB * (NFB + 1) / 2;
     constexpr int GS = DwCfg<NFB>::GS;                           // MFMA k-steps (4 entries each) per pipelined group
-    __shared__ __attribute__((aligned(16))) float Pan1[NFB * 320];           // original tiles of block row p
-    __shared__ __attribute__((aligned(16))) float Pan2[NFB * 320];           // W tiles of block row p
     __shared__ __attribute__((aligned(16))) float Wv[NFB * 16];              // w_p = X_p y_p, kept for the backward pass
     __shared__ __attribute__((aligned(16))) float Wb[BORDER ? NFB * 16 : 4]; // w^b_p = X_p b_p
     const int lane = threadIdx.x;
@@ -253,36 +252,33 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                     cacc -= b0 * wb0 + b1 * wb1 + b2 * wb2 + b3 * wb3;
                     eacc -= b0 * wv0 + b1 * wv1 + b2 * wv2 + b3 * wv3;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                // Row p: W_pj = X B_pj replaces the tile, the original goes to `orig` for the trailing update.  Both operands
+                // of that update are elements THIS lane already holds: instruction e of  B_ij -= B_pi^T W_pj  wants
+                // A[m = r][k = q] = B_pi[4q + e][r] and B[k = q][n = r] = W_pj[4q + e][r], i.e. register e of the two tiles in
+                // accumulator layout -- no LDS panel, no exchange.
+                f32x4 orig[NFB];
 #pragma unroll
                 for (int j = p + 1; j < NFB; ++j) {
                     const int t = tile_w<NFB>(p, j);
+                    orig[j] = acc[t];
                     f32x4 n = f32x4{0.f, 0.f, 0.f, 0.f};
                     n = WMF_MFMA16(X[0], acc[t][0], n); n = WMF_MFMA16(X[1], acc[t][1], n);
                     n = WMF_MFMA16(X[2], acc[t][2], n); n = WMF_MFMA16(X[3], acc[t][3], n);
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        Pan1[j * 320 + (4 * q + reg) * 20 + r] = acc[t][reg];
-                        Pan2[j * 320 + (4 * q + reg) * 20 + r] = n[reg];
-                    }
-                    acc[t] = n;                                  // W_pj stays in registers for the backward pass
+                    acc[t] = n;                                  // W_pj stays in registers for the backward pass too
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int i = p + 1; i < NFB; ++i) {
                     float a[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] = -Pan1[i * 320 + (4 * q + e) * 20 + r];
+                    for (int e = 0; e < 4; ++e) a[e] = -orig[i][e];
                     // y_i[r] -= sum_rows B_pi[row][r] w_p[row]: this lane's rows are 4q + e, a[e] = -B_pi[4q + e][r]
                     racc[i] += a[0] * wv0 + a[1] * wv1 + a[2] * wv2 + a[3] * wv3;
                     if constexpr (BORDER) bacc[i] += a[0] * wb0 + a[1] * wb1 + a[2] * wb2 + a[3] * wb3;
 #pragma unroll
                     for (int j = i; j < NFB; ++j) {
-                        const int t = tile_w<NFB>(i, j);
+                        const int t = tile_w<NFB>(i, j), tw = tile_w<NFB>(p, j);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[t] = WMF_MFMA16(a[e], Pan2[j * 320 + (4 * q + e) * 20 + r], acc[t]);
+                        for (int e = 0; e < 4; ++e) acc[t] = WMF_MFMA16(a[e], acc[tw][e], acc[t]);
                     }
                 }
             }
