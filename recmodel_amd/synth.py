@@ -13,6 +13,7 @@ CONFIGS = {
     "cfg2": (1_000_000, 100_000, 20, 64, False),
     "cfg3": (10_000_000, 1_000_000, 10, 128, True),
     "cfg4": (10_000_000, 1_000_000, 10, 128, False),  # the cfg3 matrix without biases (f = 128: eight 16-wide blocks)
+    "cfg3m": (200_000, 1_000_000, 500, 128, True),   # cfg3's item side against a cache-resident user table (kernel lab only)
     "cfg5s": (2_000_000, 200_000, 20, 256, False),   # one GPU's 1/25 slice of cfg5 (k = 256; run with --zipf 1.1 for the power law)
     "tiny": (2000, 500, 12, 16, False),
 }
