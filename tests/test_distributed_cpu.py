@@ -114,6 +114,29 @@ def test_three_ranks_all_modes(tmp_path, mode):
     np.testing.assert_allclose(got["items"], items, rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("mode", ["reduce", "pipe"])
+def test_eight_ranks(tmp_path, mode):
+    """The world size of the driver's scaling run, through the two modes it will pick there (reduce mode for the items
+    at 8 GPUs, pipelined gather at 2 and 4), on CPU ranks with the stand-in kernels."""
+    from oracle import wmf_oracle as orc
+    from recmodel_amd import synth
+    out = str(tmp_path / "out.npz")
+    kw = {"reduce": (True, None), "pipe": (False, True)}[mode]
+    mp.spawn(_worker, args=(8, _free_port(), False, out, kw[0], kw[1]), nprocs=8, join=True)
+    got = np.load(out)
+    n_users, n_items, dim = 203, 57, 6
+    indptr, indices, counts = synth.make_counts(n_users, n_items, 5, seed=11)
+    C = synth.to_scipy(indptr, indices, counts, (n_users, n_items)).astype(np.float64)
+    C.data = 10 * np.log(1 + C.data)
+    CT = C.T.tocsr()
+    items = orc.init_items(n_items, dim, False)
+    for _ in range(2):
+        users = orc.recompute_factors(items, C, 0.1)
+        items = orc.recompute_factors(users, CT, 0.1)
+    np.testing.assert_allclose(got["users"], users, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(got["items"], items, rtol=2e-4, atol=2e-5)
+
+
 def test_single_rank_engine_with_stand_in_matches_oracle():
     """world = 1 through the same code path (no process group)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
