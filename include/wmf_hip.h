@@ -131,6 +131,15 @@ int wmf_rank_topn(const float* users, const float* items, int f, int ld, int bia
                   const int32_t* cand_idx, int64_t n_cand, int64_t topn, int32_t* out_pos, float* out_scores,
                   void* workspace, int64_t workspace_bytes, void* stream);
 
+/* WMF.rank with a LIST of users (wmf_model.py:29-32 loops; here one launch): every user in user_idx (n_users,
+ * device) against the same candidate list; out_pos[u * topn + k] = position in cand_idx of user u's k-th best.
+ * Scores by f32 MFMA (16 users x 16 candidates per wave), ordering by a stable segmented radix sort.
+ * n_users * n_cand < 2^31; workspace: wmf_rank_batch_workspace_bytes(n_users, n_cand). */
+int64_t wmf_rank_batch_workspace_bytes(int64_t n_users, int64_t n_cand);
+int wmf_rank_topn_batch(const float* users, const float* items, int f, int ld, int bias, const int32_t* user_idx,
+                        int64_t n_users, const int32_t* cand_idx, int64_t n_cand, int64_t topn, int32_t* out_pos,
+                        float* out_scores, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* RecModel.eval_topn / compute_hit, base_model.py:51-148, for all test entries at once.
  * Test entry p = (pair_user[p], pair_item[p]); its user's random candidates are row pair_row[p] of
  * candidates[n_rows][n_cand] (item rows, drawn by the caller exactly as base_model.py:62-63 draws them) and

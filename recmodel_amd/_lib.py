@@ -43,6 +43,8 @@ SIGNATURES = {
     "wmf_eliminate_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "wmf_rank_workspace_bytes": (c_i64, [c_i64]),
     "wmf_rank_topn": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "wmf_rank_batch_workspace_bytes": (c_i64, [c_i64, c_i64]),
+    "wmf_rank_topn_batch": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wmf_hit_counts": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "wmf_spmm_rows": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "wmf_confidence_transform": (c_int, [c_vp, c_i64, c_dbl, c_dbl, c_int, c_vp]),

@@ -334,6 +334,25 @@ int wmf_rank_topn(const float* users, const float* items, int f, int ld, int bia
     return check_launch("wmf_rank_topn");
 }
 
+int64_t wmf_rank_batch_workspace_bytes(int64_t n_users, int64_t n_cand) { return wmf_rank_batch_ws_bytes(n_users, n_cand); }
+
+int wmf_rank_topn_batch(const float* users, const float* items, int f, int ld, int bias, const int32_t* user_idx, int64_t n_users,
+                        const int32_t* cand_idx, int64_t n_cand, int64_t topn, int32_t* out_pos, float* out_scores,
+                        void* workspace, int64_t workspace_bytes, void* stream) {
+    int rc = check_shape(f, ld);
+    if (rc) return rc;
+    if (!users || !items || !user_idx || !cand_idx || !out_pos || !workspace) { wmf_set_error("wmf_rank_topn_batch: null pointer"); return WMF_EINVAL; }
+    if (n_users < 1 || n_cand < 1 || topn < 1 || topn > n_cand || n_users * n_cand >= ((int64_t)1 << 31)) {
+        wmf_set_error("wmf_rank_topn_batch: need n_users, n_cand >= 1, 1 <= topn <= n_cand, n_users * n_cand < 2^31");
+        return WMF_EINVAL;
+    }
+    const int lrc = wmf_launch_rank_batch(users, items, f, ld, bias, user_idx, n_users, cand_idx, n_cand, topn, out_pos, out_scores,
+                                          workspace, workspace_bytes, (hipStream_t)stream);
+    if (lrc == -3) { wmf_set_error("wmf_rank_topn_batch: workspace too small"); return WMF_EINVAL; }
+    if (lrc) { wmf_set_error("wmf_rank_topn_batch: device sort failed"); return WMF_EHIP; }
+    return check_launch("wmf_rank_topn_batch");
+}
+
 int wmf_hit_counts(const float* users, const float* items, int f, int ld, int bias, const int32_t* pair_user,
                    const int32_t* pair_item, const int32_t* pair_row, int64_t n_pairs, const int32_t* candidates,
                    int32_t n_cand, const int32_t* slot, const int32_t* topn, int32_t n_topn, int64_t* hits, void* stream) {

@@ -86,6 +86,10 @@ int64_t wmf_rank_ws_bytes(int64_t n);
 int wmf_launch_rank(const float* users, const float* items, int f, int ld, int bias, const int32_t* user_idx,
                     const int32_t* cand, int64_t n, int64_t topn, int32_t* out_pos, float* out_scores, void* ws,
                     int64_t ws_bytes, hipStream_t st);
+int64_t wmf_rank_batch_ws_bytes(int64_t nu, int64_t nc);
+int wmf_launch_rank_batch(const float* users, const float* items, int f, int ld, int bias, const int32_t* user_idx, int64_t nu,
+                          const int32_t* cand, int64_t nc, int64_t topn, int32_t* out_pos, float* out_scores, void* ws,
+                          int64_t ws_bytes, hipStream_t st);
 int wmf_launch_confidence(float* values, int64_t nnz, double alpha, double beta, int mode, hipStream_t st);
 
 void wmf_set_error(const char* fmt, ...);

@@ -55,6 +55,104 @@ __global__ __launch_bounds__(256) void hit_kernel(const float* __restrict__ user
     }
 }
 
+// ---- batched rank: many users against one candidate list ------------------------------------------------
+// scores[u][c] for 16 users x 16 candidates per wave by f32 MFMA: both operands are row gathers of 16-byte pieces
+// (lane (r, q) reads piece 4 kk + q of user r and of candidate r), exactly the S = V V^T pattern of wmf_solve.hip.
+// bias: the column-0 product is left out and users[u][0] + items[c][0] added (wmf_model.py:209-211).
+__global__ __launch_bounds__(256) void score_tile_kernel(const float* __restrict__ users, const float* __restrict__ items, int ld,
+                                                         int bias, const int32_t* __restrict__ user_idx, int64_t nu,
+                                                         const int32_t* __restrict__ cand_idx, int64_t nc,
+                                                         float* __restrict__ scores) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int nch = ld >> 2;
+    const int64_t tiles_c = (nc + 15) >> 4, tiles = ((nu + 15) >> 4) * tiles_c;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t tu = tile / tiles_c, tc = tile % tiles_c;
+        const int64_t uu = min(16 * tu + r, nu - 1), cc = min(16 * tc + r, nc - 1);          // clamped: stores are masked
+        const float4* urow = reinterpret_cast<const float4*>(users + (int64_t)user_idx[uu] * ld);
+        const float4* irow = reinterpret_cast<const float4*>(items + (int64_t)cand_idx[cc] * ld);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        float ub = 0.f, ib = 0.f;
+        for (int c = q; c < ((nch + 3) & ~3); c += 4) {           // uniform trip count; pieces past the row are zero
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (c < nch) { a = urow[c]; b = irow[c]; }
+            if (bias && c == 0) { ub = a.x; ib = b.x; a.x = 0.f; }
+            acc = WMF_MFMA16(a.x, b.x, acc); acc = WMF_MFMA16(a.y, b.y, acc);
+            acc = WMF_MFMA16(a.z, b.z, acc); acc = WMF_MFMA16(a.w, b.w, acc);
+        }
+        // acc[reg] = score(user 16 tu + 4 q + reg, candidate 16 tc + r); the biases sit in the q = 0 lanes
+        const float ibr = __shfl(ib, r);                           // item bias of candidate r
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float ubr = __shfl(ub, 4 * q + reg);             // user bias of user 4 q + reg
+            const int64_t urow_i = 16 * tu + 4 * q + reg, ccol = 16 * tc + r;
+            if (urow_i < nu && ccol < nc) scores[urow_i * nc + ccol] = acc[reg] + (bias ? ubr + ibr : 0.f);
+        }
+    }
+}
+
+__global__ void batch_index_kernel(int32_t* __restrict__ pos, int32_t* __restrict__ offsets, int64_t nu, int64_t nc) {
+    const int64_t n = nu * nc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) pos[i] = (int32_t)(i % nc);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nu; i += (int64_t)gridDim.x * blockDim.x) offsets[i] = (int32_t)(i * nc);
+}
+
+__global__ void take_top_kernel(const int32_t* __restrict__ spos, const float* __restrict__ sscore, int64_t nu, int64_t nc,
+                                int64_t topn, int32_t* __restrict__ out_pos, float* __restrict__ out_scores) {
+    const int64_t n = nu * topn;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t u = i / topn, k = i % topn;
+        out_pos[i] = spos[u * nc + k];
+        if (out_scores) out_scores[i] = sscore[u * nc + k];
+    }
+}
+
+static size_t batch_sort_temp_bytes(int64_t nu, int64_t nc) {
+    size_t bytes = 0;
+    (void)rocprim::segmented_radix_sort_pairs_desc(nullptr, bytes, (float*)nullptr, (float*)nullptr, (int32_t*)nullptr,
+                                                   (int32_t*)nullptr, (unsigned)(nu * nc), (unsigned)nu, (int32_t*)nullptr,
+                                                   (int32_t*)nullptr, 0, 32, (hipStream_t)0);
+    return bytes;
+}
+
+// workspace: [scores nu*nc][sorted scores][positions][sorted positions][offsets nu+1][rocPRIM temporary]
+int64_t wmf_rank_batch_ws_bytes(int64_t nu, int64_t nc) {
+    if (nu <= 0 || nc <= 0) return 256;
+    const size_t arr = (((size_t)nu * nc * 4 + 255) / 256) * 256, off = (((size_t)(nu + 1) * 4 + 255) / 256) * 256;
+    return (int64_t)(4 * arr + off + batch_sort_temp_bytes(nu, nc) + 256);
+}
+
+int wmf_launch_rank_batch(const float* users, const float* items, int f, int ld, int bias, const int32_t* user_idx, int64_t nu,
+                          const int32_t* cand, int64_t nc, int64_t topn, int32_t* out_pos, float* out_scores, void* ws,
+                          int64_t ws_bytes, hipStream_t st) {
+    (void)f;
+    if (nu <= 0 || nc <= 0) return 0;
+    if (nu * nc >= (int64_t)1 << 31) return -4;
+    if (ws_bytes < wmf_rank_batch_ws_bytes(nu, nc)) return -3;
+    const size_t arr = (((size_t)nu * nc * 4 + 255) / 256) * 256, off = (((size_t)(nu + 1) * 4 + 255) / 256) * 256;
+    char* base = static_cast<char*>(ws);
+    float* scores = reinterpret_cast<float*>(base);
+    float* sorted = reinterpret_cast<float*>(base + arr);
+    int32_t* pos = reinterpret_cast<int32_t*>(base + 2 * arr);
+    int32_t* spos = reinterpret_cast<int32_t*>(base + 3 * arr);
+    int32_t* offsets = reinterpret_cast<int32_t*>(base + 4 * arr);
+    void* temp = base + 4 * arr + off;
+    size_t temp_bytes = batch_sort_temp_bytes(nu, nc);
+    const int64_t tiles = ((nu + 15) / 16) * ((nc + 15) / 16);
+    int64_t grid = (tiles + 3) / 4;
+    if (grid > 16384) grid = 16384;
+    {
+        WmfProfScope ps(WMF_SLOT_PREDICT, st);
+        hipLaunchKernelGGL(score_tile_kernel, dim3((unsigned)grid), dim3(256), 0, st, users, items, ld, bias, user_idx, nu, cand, nc,
+                           scores);
+    }
+    hipLaunchKernelGGL(batch_index_kernel, dim3(2048), dim3(256), 0, st, pos, offsets, nu, nc);
+    if (rocprim::segmented_radix_sort_pairs_desc(temp, temp_bytes, scores, sorted, pos, spos, (unsigned)(nu * nc), (unsigned)nu,
+                                                 offsets, offsets + 1, 0, 32, st) != hipSuccess) return -2;
+    hipLaunchKernelGGL(take_top_kernel, dim3(1024), dim3(256), 0, st, spos, sorted, nu, nc, topn, out_pos, out_scores);
+    return 0;
+}
+
 __global__ void iota_kernel(int32_t* __restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (int32_t)i;
 }

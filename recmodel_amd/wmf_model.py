@@ -96,12 +96,15 @@ class WMF(RecModel):
         Scores and ordering both happen on the device (wmf_rank_topn); equal scores keep candidate order."""
         if topn is None:
             topn = len(items)
-        if isinstance(users, list):
-            return [self.rank(items, user, topn) for user in users]
         if not type(items) == np.ndarray:
             items = np.array(items)
         n = len(items)
         keep = min(int(topn), n)
+        if isinstance(users, list):
+            # the reference recurses user by user (wmf_model.py:29-32); here all of them in one device call per batch
+            if keep <= 0 or len(users) == 0:
+                return [items[:0] for _ in users]
+            return self._rank_many(items, users, keep)
         if keep <= 0:
             return items[:0]
         u = int(np.asarray(users).reshape(-1)[0])
@@ -119,6 +122,36 @@ class WMF(RecModel):
         _lib.check(lib.wmf_rank_topn(_ptr(users_t), _ptr(items_t), f, ld, int(self.bias is True), _ptr(ut), _ptr(it), n, keep,
                                      _ptr(pos), None, _ptr(ws), ws_bytes, _stream()))
         return items[pos.cpu().numpy()]
+
+    def _rank_many(self, items, users, keep):
+        """rank() for a list of users: scores of 16 x 16 (user, candidate) tiles by MFMA, one segmented sort
+        (wmf_rank_topn_batch), in batches of at most 2^26 scores."""
+        n = len(items)
+        u = np.asarray(users).reshape(-1).astype(np.int64)
+        idx = np.asarray(items).astype(np.int64)
+        if (u.min() < -self.users.shape[0] or u.max() >= self.users.shape[0] or idx.min() < -self.items.shape[0]
+                or idx.max() >= self.items.shape[0]):
+            raise IndexError("user or item index out of bounds")
+        u = np.where(u < 0, u + self.users.shape[0], u).astype(np.int32)
+        idx = np.where(idx < 0, idx + self.items.shape[0], idx).astype(np.int32)
+        users_t, items_t, f, ld = self._device_factors()
+        lib = _lib.load()
+        it = torch.from_numpy(idx).cuda()
+        per = max(1, min(len(u), (1 << 26) // max(n, 1)))
+        out = []
+        ws = None
+        for b0 in range(0, len(u), per):
+            ub = torch.from_numpy(u[b0: b0 + per]).cuda()
+            nu = ub.numel()
+            need = int(lib.wmf_rank_batch_workspace_bytes(nu, n))
+            if ws is None or ws.numel() < need:
+                ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+            pos = torch.empty(nu * keep, dtype=torch.int32, device="cuda")
+            _lib.check(lib.wmf_rank_topn_batch(_ptr(users_t), _ptr(items_t), f, ld, int(self.bias is True), _ptr(ub), nu, _ptr(it), n,
+                                               keep, _ptr(pos), None, _ptr(ws), ws.numel(), _stream()))
+            ph = pos.cpu().numpy().reshape(nu, keep)
+            out.extend(items[ph[j]] for j in range(nu))
+        return out
 
     def _hit_counts(self, pair_user, pair_item, pair_row, candidates, slot, topn):
         """compute_hit (base_model.py:51-98) for every test entry in one launch: wmf_hit_counts."""

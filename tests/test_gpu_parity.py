@@ -147,6 +147,20 @@ def test_rank_full_catalogue_on_device():
         gs = np.array([sc[i] for i in got])
         np.testing.assert_allclose(gs, [sc[i] for i in want], rtol=0, atol=2e-5)       # same scores position by position
         assert (np.diff(gs) <= 2e-5).all()                                                  # best first
+    # a list of users: one batched device call (MFMA score tiles + segmented sort) instead of the reference's loop
+    sub = cand[:5000]
+    Uf, If = m.users.astype(np.float64), m.items.astype(np.float64)
+    who = [3, 0, 63, 17, 3] + list(range(20, 45))
+    many = m.rank(sub, who, topn=25)
+    assert isinstance(many, list) and len(many) == len(who)
+    for usr, got in zip(who, many):
+        sc_u = orc.predict(Uf, If, [usr], sub, True)
+        lut = dict(zip(sub.tolist(), sc_u.tolist()))
+        np.testing.assert_allclose([lut[i] for i in got], np.sort(sc_u)[::-1][:25], rtol=0, atol=3e-5)
+    # ... and agrees with the one-user entry point
+    sc17 = dict(zip(sub.tolist(), orc.predict(Uf, If, [17], sub, True).tolist()))
+    np.testing.assert_allclose([sc17[i] for i in m.rank(sub, 17, topn=25)], [sc17[i] for i in many[3]], rtol=0, atol=3e-5)
+    assert m.rank(cand[:7], [], topn=3) == []
     assert len(m.rank(cand[:5], 3, topn=50)) == 5                                            # topn beyond the list: all of it
     with pytest.raises(IndexError):
         m.rank(np.array([0, n_items]), 3, topn=1)

@@ -23,3 +23,7 @@ print(f"eval_prec: {time.perf_counter() - t0:.2f} s, mse {mse:.4f}; factors {m.u
 t0 = time.perf_counter()
 top = m.rank(np.arange(n_items), 12345, topn=10)
 print(f"rank over the whole catalogue: {time.perf_counter() - t0:.3f} s -> {top}")
+t0 = time.perf_counter()
+tops = m.rank(np.arange(n_items), list(range(0, 2000)), topn=10)
+dt = time.perf_counter() - t0
+print(f"rank for 2000 users over the whole catalogue in one call: {dt:.3f} s ({2000 / dt:.0f} users/s), first: {tops[0][:5]}")
