@@ -124,7 +124,7 @@ def measured_traffic(config, slot, f, ld):
     import glob
     nfb, nch = (f + 15) // 16, (ld + 15) // 16
     nfb_heavy = f // 16 if (f > 16 and f % 16 == 1 and (f // 16) % 4 != 3) else nfb     # border variant of the heavy-row kernel
-    key = {0: f"gram_kernel<{nfb}, 1>", 3: f"transform_kernel<{nfb}, true", 4: f"solve_low_kernel<{nch}, 1>",
+    key = {0: f"gram_kernel<{nfb}, 1>", 3: f"transform_kernel<{nfb}, true", 4: f"solve_low_kernel<{nch}, 1,",
            5: f"solve_low_kernel<{nch}, 2", 11: f"solve_directw_kernel<{nfb_heavy}, 0"}.get(slot)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config}_traffic.json")))
     if not key or not files:
