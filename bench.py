@@ -147,6 +147,12 @@ def main():
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    force_exchange = world == 1 and os.environ.get("WMF_FORCE_EXCHANGE") == "1"
+    if force_exchange:      # rehearsal: one rank through the chunked exchange path, collectives over real RCCL (engine.py)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local_rank}"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -305,7 +311,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_exchange:
         torch.distributed.destroy_process_group()
 
 

@@ -166,9 +166,15 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, wmf_plan** out) {
     for (int b = 0; b < WMF_NBINS; ++b) fill[b] = start[b];
     // within the MFMA bin: ordinary rows first, rows with more than WMF_HEAVY_T entries last (split into segments)
     std::vector<int32_t> heavy;
+    // first bin: rows with at most 8 entries first (two of them share a wave), the others behind them
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t d = indptr[r + 1] - indptr[r];
+        if (d <= 8) { order[(size_t)fill[WMF_BIN_LOW16]++] = (int32_t)r; p->count8++; }
+    }
     for (int64_t r = 0; r < n; ++r) {
         const int64_t d = indptr[r + 1] - indptr[r];
         const int b = bin_of(d, f);
+        if (b == WMF_BIN_LOW16 && d <= 8) continue;
         if (b == WMF_BIN_MFMA && d > WMF_HEAVY_T) { heavy.push_back((int32_t)r); continue; }
         order[(size_t)fill[b]++] = (int32_t)r;
     }

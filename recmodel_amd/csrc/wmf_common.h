@@ -41,6 +41,18 @@ __device__ __forceinline__ void wmf_row16_sum4(float& a, float& b, float& c, flo
 #undef WMF_STAGE
 }
 
+// the same over the two 8-lane halves of each DPP row (lanes 16g .. 16g+7 and 16g+8 .. 16g+15) separately
+__device__ __forceinline__ void wmf_row8_sum4(float& a, float& b, float& c, float& d) {
+#define WMF_STAGE(ctrl)                                                  \
+    "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile("s_nop 1\n\t" WMF_STAGE("quad_perm:[1,0,3,2]") WMF_STAGE("quad_perm:[2,3,0,1]") WMF_STAGE("row_half_mirror")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef WMF_STAGE
+}
+
 __device__ __forceinline__ double wmf_wave_sum_f64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -16,6 +16,7 @@ struct wmf_plan {
     int64_t n;                 // rows
     int f;
     int64_t count[WMF_NBINS];  // rows per bin
+    int64_t count8;            // rows of the first bin with at most 8 entries; they come first in rows[WMF_BIN_LOW16]
     int64_t nnz[WMF_NBINS];    // stored entries per bin
     int32_t* rows[WMF_NBINS];  // device: row ids of each bin (slices of rows_all)
     int32_t* rows_all;         // device: n row ids grouped by bin

@@ -300,6 +300,96 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : 1) void solve_l
     }
 }
 
+// ------------------------------------------------------------------------------ rows with d <= 8
+// TWO rows per wave: row A's entries in lanes r = 0..7 of every 16-lane group, row B's in r = 8..15.  The one
+// 16 x 16 S tile then holds S_A and S_B on its diagonal 8 x 8 blocks (the cross blocks are dropped when M = I + D S is
+// formed), one Gauss-Jordan sweep solves both systems (steps 0..7 belong to A, 8..15 to B), and the DPP sums of
+// g = V_u^T c stop after three stages: half the MFMAs and two thirds of the VALU work per row of solve_low<NCH, 1>.
+// A third of cfg3's users (Poisson(10) degrees) and most users of a power-law data set are such rows.
+template <int NCH>
+__global__ __launch_bounds__(256, NCH <= 9 ? 6 : 1) void solve_pair_kernel(const int32_t* __restrict__ rows, int64_t count,
+                                                                          const float* __restrict__ V, const float* __restrict__ biasv,
+                                                                          const int64_t* __restrict__ indptr,
+                                                                          const int32_t* __restrict__ indices,
+                                                                          const float* __restrict__ vals, int ld, float* __restrict__ g,
+                                                                          int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t pid = (int64_t)blockIdx.x * 4 + wave;
+    if (2 * pid >= count) return;                    // whole wave exits together
+    const bool hasB = 2 * pid + 1 < count;
+    const int uA = __builtin_amdgcn_readfirstlane(rows[2 * pid]);
+    const int uB = __builtin_amdgcn_readfirstlane(hasB ? rows[2 * pid + 1] : rows[2 * pid]);
+    const int64_t loA = indptr[uA], loB = indptr[uB];
+    const int dA = __builtin_amdgcn_readfirstlane((int)(indptr[uA + 1] - loA));
+    const int dB = hasB ? __builtin_amdgcn_readfirstlane((int)(indptr[uB + 1] - loB)) : 0;
+    const int r = lane & 15, q = lane >> 4;
+    const int nch = ld >> 2;
+    const bool second = r >= 8;                      // this lane's entry belongs to row B
+    const int j = r & 7;
+    const int my_d = second ? dB : dA;
+    const float am = j < my_d ? 1.f : 0.f;
+    const int64_t e = j < my_d ? (second ? loB : loA) + j : 0;     // entry 0 exists: the launcher skips matrices without entries
+    const int idx = indices[e];
+    float wj = vals[e];
+    if (biasv) wj -= biasv[idx];
+    wj *= am;
+    const bool neg = !(wj >= 0.f);                   // negative or NaN weight: needs pivoting
+    float w[1] = {wj}, p[1] = {wj + am};
+    float4 x[NCH];
+    const float4* Vq = reinterpret_cast<const float4*>(V) + q;
+    const int last_c = min(4 * (NCH - 1) + q, nch - 1);
+    const float last_m = (4 * (NCH - 1) + q < nch) ? 1.f : 0.f;
+    const float4* vrow = Vq + (int64_t)idx * nch;
+#pragma unroll
+    for (int t = 0; t < NCH - 1; ++t) x[t] = vrow[4 * t];
+    {
+        const float4 v = (vrow - q)[last_c];
+        x[NCH - 1] = make_float4(v.x * last_m, v.y * last_m, v.z * last_m, v.w * last_m);
+    }
+    auto bounce = [&]() {                            // both rows go to the pivoted LU kernel
+        if (lane == 0) {
+            const int at = atomicAdd(fb_count, hasB ? 2 : 1);
+            fb_rows[at] = uA;
+            if (hasB) fb_rows[at + 1] = uB;
+        }
+    };
+    if (__any(neg)) { bounce(); return; }
+
+    int baddr[4];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) baddr[kq] = (r + 16 * kq) * 4;
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+        a0 = WMF_MFMA16(x[t].x, x[t].x, a0);
+        a1 = WMF_MFMA16(x[t].y, x[t].y, a1);
+        a0 = WMF_MFMA16(x[t].z, x[t].z, a0);
+        a1 = WMF_MFMA16(x[t].w, x[t].w, a1);
+    }
+    // M = I + D S restricted to the two diagonal 8 x 8 blocks: this lane's columns are 4q + reg, i.e. block q >> 1
+    const float keep = (second == (q >= 2)) ? 1.f : 0.f;
+    float m[1][4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) m[0][reg] = w[0] * keep * (a0[reg] + a1[reg]) + ((r == 4 * q + reg) ? 1.f : 0.f);
+    if (0 < dA) { gj_step<0, 1>(m, p, baddr, r); gj_step<1, 1>(m, p, baddr, r); gj_step<2, 1>(m, p, baddr, r); gj_step<3, 1>(m, p, baddr, r); }
+    if (4 < dA) { gj_step<4, 1>(m, p, baddr, r); gj_step<5, 1>(m, p, baddr, r); gj_step<6, 1>(m, p, baddr, r); gj_step<7, 1>(m, p, baddr, r); }
+    if (0 < dB) { gj_step<8, 1>(m, p, baddr, r); gj_step<9, 1>(m, p, baddr, r); gj_step<10, 1>(m, p, baddr, r); gj_step<11, 1>(m, p, baddr, r); }
+    if (4 < dB) { gj_step<12, 1>(m, p, baddr, r); gj_step<13, 1>(m, p, baddr, r); gj_step<14, 1>(m, p, baddr, r); gj_step<15, 1>(m, p, baddr, r); }
+    if (__any(!(fabsf(p[0]) < 3.0e38f))) { bounce(); return; }
+
+    // ---- g = V_u^T c per row: sums over the 8 lanes of a half, lanes r = 0 and r = 8 store
+    float4* grow = reinterpret_cast<float4*>(g + (int64_t)(second ? uB : uA) * ld);
+    const bool writer = j == 0 && (!second || hasB);
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+        float4 y = make_float4(p[0] * x[t].x, p[0] * x[t].y, p[0] * x[t].z, p[0] * x[t].w);
+        wmf_row8_sum4(y.x, y.y, y.z, y.w);
+        const int c = 4 * t + q;
+        if (writer && c < nch) grow[c] = y;
+    }
+}
+
 // ---------------------------------------------------------------------------------- general rows
 // One 256-thread workgroup per row.  Thread (ty, tx) = (tid >> 4, tid & 15) accumulates the
 // NFB x NFB register block B[ty + 16 i][tx + 16 j] of  B = I + V_u^T D V_u  over the row's
@@ -495,10 +585,18 @@ template <int NCH>
 static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int ld, float* g, hipStream_t st) {
     const int64_t c0 = pl->count[WMF_BIN_LOW16], c1 = pl->count[WMF_BIN_LOW32];
-    if (c0 > 0) {
+    // rows with at most 8 entries come first in the bin and go two per wave (solve_pair_kernel)
+    const int64_t c8 = (wmf_debug_flags & 2048) ? 0 : pl->count8;
+    if (c8 > 0) {
         WmfProfScope ps(WMF_SLOT_SOLVE_LOW16, st);
-        hipLaunchKernelGGL((solve_low_kernel<NCH, 1, false>), dim3((unsigned)((c0 + 3) / 4)), dim3(256), 0, st,
-                           pl->rows[WMF_BIN_LOW16], c0, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
+        hipLaunchKernelGGL((solve_pair_kernel<NCH>), dim3((unsigned)(((c8 + 1) / 2 + 3) / 4)), dim3(256), 0, st,
+                           pl->rows[WMF_BIN_LOW16], c8, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
+                           pl->fallback_count);
+    }
+    if (c0 - c8 > 0) {
+        WmfProfScope ps(WMF_SLOT_SOLVE_LOW16, st);
+        hipLaunchKernelGGL((solve_low_kernel<NCH, 1, false>), dim3((unsigned)((c0 - c8 + 3) / 4)), dim3(256), 0, st,
+                           pl->rows[WMF_BIN_LOW16] + c8, c0 - c8, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
                            pl->fallback_count);
     }
     if (c1 > 0) {

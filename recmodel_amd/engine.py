@@ -181,7 +181,7 @@ class AlsEngine:
     """Weighted-ALS state of one rank: factor blocks, whitened gathers, CSR shards."""
 
     def __init__(self, n_users, n_items, dim, bias, gamma, device=None, group=None, kernels=None, chunks=None,
-                 reduce_mode=None, pipe_mode=None):
+                 reduce_mode=None, pipe_mode=None, force_exchange=None):
         self.K = kernels if kernels is not None else HipKernels()     # raises without a GPU / built library
         self.lib = getattr(self.K, "lib", None)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -191,6 +191,14 @@ class AlsEngine:
             self.rank = torch.distributed.get_rank(group)
         else:
             self.world, self.rank = 1, 0
+        # the exchange machinery (separate gathered matrices, chunks, collectives) is what more than one rank uses; a
+        # single rank can be made to go through it as well (force_exchange / WMF_FORCE_EXCHANGE=1) so that the very
+        # RCCL calls of the multi-GPU path -- asynchronous all-gathers and reduce-scatters on RCCL's stream, ordered
+        # against the kernels by work.wait() -- can be rehearsed on a one-GPU box
+        if force_exchange is None:
+            force_exchange = os.environ.get("WMF_FORCE_EXCHANGE") == "1"
+        self.exchange = self.world > 1 or (bool(force_exchange) and torch.distributed.is_available()
+                                           and torch.distributed.is_initialized())
         self.n = {"users": int(n_users), "items": int(n_items)}
         self.dim, self.bias, self.gamma = int(dim), bool(bias), float(gamma)
         self.f = self.dim + 1 if self.bias else self.dim
@@ -207,7 +215,7 @@ class AlsEngine:
             gain = W > 1 and pr > 0 and self.rpr[s] * pr < REDUCE_GAIN * self.rpr[o] * self.ld
             # a summed system that is not positive definite cannot be handed to the pivoted fallback (no CSR at the
             # owner), and only bias-adjusted weights can go negative: with biases the mode has to be asked for
-            self.reduce[s] = W > 1 and pr > 0 and (forced == "1" or (forced is None and gain and not self.bias))
+            self.reduce[s] = self.exchange and pr > 0 and (forced == "1" or (forced is None and gain and not self.bias))
         if self.reduce["users"] and self.reduce["items"]:
             # both at once would leave nobody holding a whole side; keep the one that saves more
             keep = "items" if self.rpr["items"] <= self.rpr["users"] else "users"
@@ -216,7 +224,7 @@ class AlsEngine:
         self.pipe_mode = pipe_mode
         auto_chunks = chunks is None and "WMF_CHUNKS" not in os.environ
         if chunks is None:
-            chunks = int(os.environ.get("WMF_CHUNKS", "4")) if W > 1 else 1
+            chunks = int(os.environ.get("WMF_CHUNKS", "4")) if self.exchange else 1
         # chunk c of a side = local rows [c * chunk_len, min((c + 1) * chunk_len, rows_per_rank)).  A side whose block is
         # small is not cut when the chunk count is the default: its gather is cheap, and a few thousand heavy rows per
         # launch would leave most of the 3000 resident waves of the row kernels idle in the last round.
@@ -237,7 +245,7 @@ class AlsEngine:
         self.factors = {s: z(self.rpr[s], self.ld) for s in self.n}
         self.g = {s: z(self.rpr[s], self.ld) for s in self.n}
         # gathered factors of all ranks (chunk-major positions); with one rank the local block itself
-        self.X = {s: (z(W * self.rpr[s], self.ld) if W > 1 else self.factors[s]) for s in self.n}
+        self.X = {s: (z(W * self.rpr[s], self.ld) if self.exchange else self.factors[s]) for s in self.n}
         self._pending = {s: [] for s in self.n}                            # all-gathers in flight
         # whitened gathered factors / bias of the fixed side [W * rows_per_rank, ld]
         self.V = {s: z(W * self.rpr[s], self.ld) for s in self.n}
@@ -305,7 +313,7 @@ class AlsEngine:
         full = self.csr[side]
         forced = os.environ.get("WMF_PIPE") if self.pipe_mode is None else ("1" if self.pipe_mode else "0")
         heavy = full.nnz >= PIPE_MIN_ENTRIES * max(1, self.n_local[side]) * len(bounds)
-        self.pipe[side] = (self.world > 1 and len(bounds) > 1 and self.pr > 0 and not self.reduce[fixed]
+        self.pipe[side] = (self.exchange and len(bounds) > 1 and self.pr > 0 and not self.reduce[fixed]
                            and (forced == "1" or (forced is None and heavy and not self.bias)))
         if not self.pipe[side]:
             return
@@ -366,7 +374,7 @@ class AlsEngine:
     def _publish(self, side, c, force=False):
         """Start the all-gather of chunk ``c`` of this rank's freshly written block.  It is ordered after the
         kernels already enqueued on the current stream and runs beside whatever is enqueued next."""
-        if self.world == 1:
+        if not self.exchange:
             return
         if self.reduce[self._other(side)] and not force:
             self._stale[side] = True                 # the other side reads only this rank's block: gather on demand
@@ -397,11 +405,11 @@ class AlsEngine:
         K = self.K
         blk = self.factors[fixed]
         K.gram(blk, self.n_local[fixed], self.f, self.ld, self.bias, self.G, self.ws)
-        if self.world > 1:
+        if self.exchange:
             torch.distributed.all_reduce(self.G, group=self.group)
         K.factorize(self.G, self.f, self.ld, self.gamma, self.W_white, self.W_unwhite, self.info, self.ws)
         V, bvec = self.V[fixed], self.bias_vec[fixed]
-        if self.world == 1:
+        if not self.exchange:
             K.row_transform(self.X[fixed], self.n_local[fixed], self.f, self.ld, self.W_white, self.bias, V,
                             bvec if self.bias else None)
             return
@@ -550,7 +558,7 @@ class AlsEngine:
         self._ensure_gathered("items")
         self.K.eval_sqerr(self.factors["users"], self.X["items"], self.f, self.ld, self.bias, shard.indptr, shard.indices,
                           shard.values, shard.n_rows, self.eval_out, self.eval_ws)
-        if self.world > 1:
+        if self.exchange:
             torch.distributed.all_reduce(self.eval_out, group=self.group)
         return tuple(float(x) for x in self.eval_out.cpu())
 

@@ -230,6 +230,47 @@ def test_half_step_vs_oracle_all_degree_classes(WMF, k, bias):
         assert not np.isnan(got).any()
 
 
+@pytest.mark.parametrize("k,bias,neg", [(16, False, False), (64, False, False), (128, True, False), (130, False, False),
+                                        (64, True, True)])
+def test_short_rows_share_a_wave(WMF, k, bias, neg):
+    """Rows with at most 8 stored entries are solved two per wave (solve_pair_kernel): an odd number of such rows,
+    empty rows next to full ones, degrees 0..8 in every pairing, and -- with large fixed-side biases -- pairs in which
+    one row's weights go negative, so that BOTH rows are bounced to the pivoted kernel."""
+    from recmodel_amd import synth
+    n, m_items = 1001, 300
+    rng = np.random.default_rng(k + 7)
+    ip, idx, val = synth.make_counts(n, m_items, 3, 4242 + k)
+    C = synth.to_scipy(ip, idx, val, (n, m_items)).tolil()
+    for r in range(0, 90):                                            # every (dA, dB) combination next to each other
+        d = (r // 10, r % 10)[r % 2] % 9
+        C.rows[r] = list(np.sort(rng.choice(m_items, d, replace=False)))
+        C.data[r] = list((1 + rng.integers(0, 5, d)).astype(np.float32))
+    if sum(len(r) <= 8 for r in C.rows) % 2 == 0:                     # make the number of short rows odd
+        C.rows[100] = list(range(12))
+        C.data[100] = [2.0] * 12
+    C = C.tocsr().astype(np.float32)
+    C.data = (10 * np.log(1 + C.data)).astype(np.float32)
+    deg = np.diff(C.indptr)
+    assert (deg <= 8).sum() % 2 == 1 and (deg == 0).sum() > 0
+    model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=bias)
+    step_o = orc.recompute_factors_bias if bias else orc.recompute_factors
+    step_g = model.recompute_factors_bias if bias else model.recompute_factors
+    Y = step_o(step_o(model.items, as_f64(C), 0.1), as_f64(C.T.tocsr()), 0.1)       # trained-like item factors
+    if neg:
+        Y = Y.copy()
+        Y[:, 0] = np.where(rng.random(m_items) < 0.15, 30.0, Y[:, 0])             # some weights w - bias go negative
+    want = step_o(Y, as_f64(C), 0.1, out_dtype="float64")
+    got = step_g(Y, C, 0.1)
+    assert not np.isnan(got).any()
+    if neg:
+        ok = np.linalg.norm(want, axis=1) < 1e3
+        assert ok.mean() > 0.9 and fro(got[ok], want[ok]) <= 1e-3
+    else:
+        rel, zero_abs = worst_row(got, want)
+        assert fro(got, want) <= HALF_FRO and rel <= HALF_ROW and zero_abs == 0.0, (fro(got, want), rel, zero_abs)
+        assert np.all(got[deg == 0] == 0)
+
+
 @pytest.mark.parametrize("k", [16, 256])
 def test_negative_weights_take_the_pivoted_path(WMF, k):
     """bias model with large fixed-side biases: w - bias < 0 for many entries, so A_u is not SPD

@@ -23,11 +23,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None):
+def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import wmf_oracle as orc
         from recmodel_amd import synth
@@ -35,7 +38,9 @@ def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None)
         n_users, n_items, dim = 1203, 257, 24
         indptr, indices, counts = synth.make_counts(n_users, n_items, 9, seed=11)
         values = (10 * torch.log(1 + counts)).to(torch.float32)
-        eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cuda:0", chunks=3, reduce_mode=reduce_mode, pipe_mode=pipe_mode)
+        eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cuda:0", chunks=3, reduce_mode=reduce_mode, pipe_mode=pipe_mode,
+                        force_exchange=True)
+        assert eng.exchange and len(eng.chunk_bounds["users"]) == 3
         assert eng.reduce["items"] == bool(reduce_mode)
         eng_pipe_expected = bool(pipe_mode)
         eng.set_interactions(indptr, indices, values)
@@ -66,7 +71,12 @@ def test_two_ranks_one_gpu_match_oracle(tmp_path, bias, reduce_mode, pipe_mode):
         if "gloo" in str(exc).lower() and "cuda" in str(exc).lower():
             pytest.skip(f"gloo cannot move device tensors here: {exc}")
         raise
-    got = np.load(out)
+    _check_against_oracle(np.load(out), bias)
+
+
+def _check_against_oracle(got, bias):
+    from oracle import wmf_oracle as orc
+    from recmodel_amd import synth
     n_users, n_items, dim = 1203, 257, 24
     indptr, indices, counts = synth.make_counts(n_users, n_items, 9, seed=11)
     raw = synth.to_scipy(indptr, indices, counts, (n_users, n_items))
@@ -82,6 +92,17 @@ def test_two_ranks_one_gpu_match_oracle(tmp_path, bias, reduce_mode, pipe_mode):
     assert np.linalg.norm(got["items"] - items) <= 1e-3 * np.linalg.norm(items)
     mse = orc.eval_prec(users, items, raw, bias)
     assert abs(got["sums"][0] / got["sums"][2] - mse) <= 1e-4 * mse
+
+
+@pytest.mark.parametrize("bias,reduce_mode,pipe_mode", [(False, None, None), (True, None, None), (False, True, None),
+                                                        (True, True, None), (False, False, True), (True, False, True)])
+def test_one_rank_over_rccl_matches_oracle(tmp_path, bias, reduce_mode, pipe_mode):
+    """The RCCL calls of the multi-GPU path themselves (backend nccl: all_reduce of the fp64 Gramian, asynchronous
+    all_gather_into_tensor / reduce_scatter_tensor on RCCL's stream, work.wait() ordering against the kernels) with a
+    world of ONE rank forced through the exchange machinery (force_exchange): 3 chunks per side, all three modes."""
+    out = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(1, _free_port(), bias, out, reduce_mode, pipe_mode, "nccl"), nprocs=1, join=True)
+    _check_against_oracle(np.load(out), bias)
 
 
 def _tiny_worker(rank, world, port, mode, out_path):

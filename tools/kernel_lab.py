@@ -40,5 +40,5 @@ for fl in flags:
     lib.wmf_profile_enable(0)
     ms = np.zeros(_lib.WMF_PROF_SLOTS); ln = np.zeros(_lib.WMF_PROF_SLOTS, dtype=np.int64)
     lib.wmf_profile_read(ms.ctypes.data_as(ctypes.c_void_p), ln.ctypes.data_as(ctypes.c_void_p))
-    print(f"flags={fl}: " + ", ".join(f"{lib.wmf_profile_slot_name(s).decode()}={ms[s]/ln[s]:.3f}ms" for s in range(_lib.WMF_PROF_SLOTS) if ln[s]))
+    print(f"flags={fl}: " + ", ".join(f"{lib.wmf_profile_slot_name(s).decode()}={ms[s]/reps:.3f}ms/{ln[s]//reps}" for s in range(_lib.WMF_PROF_SLOTS) if ln[s]))
 lib.wmf_debug_set_flags(0)
