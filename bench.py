@@ -138,6 +138,11 @@ def measured_traffic(config, slot, f, ld):
 
 def main():
     args = parse()
+    # stdout carries exactly one line, the JSON result: RCCL prints a version banner to stdout when a communicator is
+    # created, so fd 1 is pointed at stderr for the run and the result goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -310,7 +315,8 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or force_exchange:
         torch.distributed.destroy_process_group()
 

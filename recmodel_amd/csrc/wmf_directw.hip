@@ -56,6 +56,9 @@
 #ifndef WMF_DW_OCC4
 #define WMF_DW_OCC4 3
 #endif
+#ifndef WMF_DW_GJ_LDS
+#define WMF_DW_GJ_LDS -1          // multiplier column of the tile inverse: 1 = ds_bpermute, 0 = two VALU lane swaps, -1 = by occupancy
+#endif
 template <int NFB>
 struct DwCfg {
     static constexpr int GS = (NFB <= 4) ? WMF_DW_GS : WMF_DW_GS_WIDE;
@@ -230,7 +233,8 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
 #pragma unroll
             for (int p = 0; p < NFB; ++p) {
                 f32x4 X = acc[tile_w<NFB>(p, p)];
-                gj_inv_sweep(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
+                constexpr bool GJ_LDS = WMF_DW_GJ_LDS < 0 ? (DwCfg<NFB>::OCC > 1) : (WMF_DW_GJ_LDS != 0);
+                gj_inv_sweep<GJ_LDS, true>(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
                 // y_p[r] complete (its four q shares added), then w_p = X y_p: lane (r, q) has X[4q + reg][r] (X is
                 // symmetric), so the products summed over the 16 lanes of a DPP row give w_p[4q + reg] on the whole row
                 float yp = racc[p];
