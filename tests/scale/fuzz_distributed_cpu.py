@@ -1,12 +1,12 @@
 """Randomised sweep of the multi-rank host logic on CPU ranks (gloo, stand-in kernels): world size, shapes, chunk counts
 and exchange mode are drawn at random; the sharded result must equal the single-process oracle.  Not a pytest.
-Usage: python tools/fuzz_distributed_cpu.py [cases] [seed]"""
+Usage: python tests/scale/fuzz_distributed_cpu.py [cases] [seed]"""
 import os, socket, sys, tempfile
 import numpy as np, torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def worker(rank, world, port, cfg, out_path):

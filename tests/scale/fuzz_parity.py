@@ -1,7 +1,7 @@
 """Randomised parity sweep (not a pytest): many (k, bias, shape, degree law) combinations, one half step each through the
 host entry point against the C oracle (oracle/wmf_oracle.c, float64).  Widths are drawn to hit every kernel family and
 the boundaries between them (f = 16, 17, 32, 33, 48, 49, 64, 65, 113, 128, 129, 144, 145, 160, 161, 256, 257, 258, 260).
-Usage: python tools/fuzz_parity.py [cases] [seed]"""
+Usage: python tests/scale/fuzz_parity.py [cases] [seed]"""
 import sys, time
 import numpy as np, scipy.sparse as sp
 sys.path.insert(0, '.')

@@ -1,6 +1,6 @@
 """Kernel-by-kernel diagnostic on a real GPU: prints error norms of each C-ABI building block
 against NumPy (fp64) so a failing parity test can be localised from one gpurun call.
-Usage: python tools/gpu_diag.py [k] [bias]"""
+Usage: python tests/scale/gpu_diag.py [k] [bias]"""
 import ctypes, sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')

@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, '.')
 from recmodel_amd import _lib, synth
 from recmodel_amd.engine import AlsEngine
-from oracle import wmf_oracle as orc
+from recmodel_amd import WMF
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 n_users, n_items, dbar, k, bias = synth.CONFIGS[cfg]
@@ -12,7 +12,7 @@ ip, idx, val = synth.make_counts(n_users, n_items, dbar, 1995, device="cuda")
 val = 10 * torch.log(1 + val)
 eng = AlsEngine(n_users, n_items, k, bias, 0.1)
 eng.set_interactions(ip, idx, val)
-eng.set_factors("items", orc.init_items(n_items, k, bias))
+eng.set_factors("items", WMF(num_items=n_items, num_users=1, dim=k, gamma=0.1, weighted=True, bias=bias).items)
 def step():
     eng.half_step("users"); eng.half_step("items")
 for _ in range(3): step()
