@@ -75,9 +75,18 @@ __device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for
 // Rows with more than WMF_HEAVY_T entries are split (power-law degrees):
 // MODE 1: one wave per SEGMENT of such a row: accumulate its WMF_SEG entries, store the partial tiles;
 // MODE 2: one wave per heavy row: add the partial tiles of its segments in order, then eliminate.
-// floats per segment in the partial buffer of split rows: the tiles [tile][reg][lane], then y [fb][lane], then
-// (BORDER) b [fb][lane], c [lane], e [lane]
-#define WMF_DW_PARTIAL(NFB, BORDER) (((NFB) * ((NFB) + 1) / 2 * 4 + (NFB) + ((BORDER) ? (NFB) + 2 : 0)) * 64)
+// floats per segment in the partial buffer of split rows: the tiles in tile_w order -- an off-diagonal tile as
+// [reg][lane] (256 floats), a diagonal tile as its upper triangle only (136 floats, element (row <= col) at
+// col (col + 1) / 2 + row: partial systems cross xGMI in reduce mode, and the lower triangle is the same numbers) --
+// then y [fb][lane], then (BORDER) b [fb][lane], c [lane], e [lane]
+#define WMF_DW_TRI 136
+#define WMF_DW_TILES(NFB) (((NFB) * ((NFB) - 1) / 2) * 256 + (NFB) * WMF_DW_TRI)
+#define WMF_DW_PARTIAL(NFB, BORDER) (WMF_DW_TILES(NFB) + ((NFB) + ((BORDER) ? (NFB) + 2 : 0)) * 64)
+template <int NFB>
+__device__ __host__ constexpr int tile_off(int bi, int bj) {     // float offset of tile (bi, bj) in a partial system
+    const int t = bi * NFB - (bi * (bi - 1)) / 2 + (bj - bi), ndiag = bi + (bj > bi ? 1 : 0);
+    return (t - ndiag) * 256 + ndiag * WMF_DW_TRI;
+}
 
 template <int NFB, int MODE, bool BORDER>
 __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(const int32_t* __restrict__ rows, int64_t count,
@@ -188,16 +197,26 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
         if constexpr (MODE == 1) {                               // partial tiles of this segment: [tile][reg][lane]
             float* out = partial + (it * slot_a + slot_b) * (int64_t)WMF_DW_PARTIAL(NFB, BORDER);   // slot of work item `it`
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int bi = 0; bi < NFB; ++bi) {
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) out[(t * 4 + reg) * 64 + lane] = acc[t][reg];
+                for (int bj = bi; bj < NFB; ++bj) {
+                    const int t = tile_w<NFB>(bi, bj);
+                    float* to = out + tile_off<NFB>(bi, bj);
 #pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) out[(NT * 4 + fb) * 64 + lane] = racc[fb];
+                    for (int reg = 0; reg < 4; ++reg) {
+                        if (bi != bj) to[reg * 64 + lane] = acc[t][reg];
+                        else if (4 * q + reg <= r) to[r * (r + 1) / 2 + 4 * q + reg] = acc[t][reg];   // element (4q + reg, r)
+                    }
+                }
+            }
+            float* vo = out + WMF_DW_TILES(NFB);
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) vo[fb * 64 + lane] = racc[fb];
             if constexpr (BORDER) {
 #pragma unroll
-                for (int fb = 0; fb < NFB; ++fb) out[(NT * 4 + NFB + fb) * 64 + lane] = bacc[fb];
-                out[(NT * 4 + 2 * NFB) * 64 + lane] = cacc;
-                out[(NT * 4 + 2 * NFB + 1) * 64 + lane] = eacc;
+                for (int fb = 0; fb < NFB; ++fb) vo[(NFB + fb) * 64 + lane] = bacc[fb];
+                vo[2 * NFB * 64 + lane] = cacc;
+                vo[(2 * NFB + 1) * 64 + lane] = eacc;
             }
             u = un; lo = lon; d = dn;
             continue;
@@ -208,16 +227,26 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
             for (int64_t sgm = sg0; sgm < sg1; ++sgm) {
                 const float* in = partial + sgm * (int64_t)WMF_DW_PARTIAL(NFB, BORDER);
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int bi = 0; bi < NFB; ++bi) {
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) acc[t][reg] += in[(t * 4 + reg) * 64 + lane];
+                    for (int bj = bi; bj < NFB; ++bj) {
+                        const int t = tile_w<NFB>(bi, bj);
+                        const float* ti = in + tile_off<NFB>(bi, bj);
 #pragma unroll
-                for (int fb = 0; fb < NFB; ++fb) racc[fb] += in[(NT * 4 + fb) * 64 + lane];
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int row = 4 * q + reg, lo_ = min(row, r), hi_ = max(row, r);
+                            acc[t][reg] += (bi != bj) ? ti[reg * 64 + lane] : ti[hi_ * (hi_ + 1) / 2 + lo_];
+                        }
+                    }
+                }
+                const float* vi = in + WMF_DW_TILES(NFB);
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) racc[fb] += vi[fb * 64 + lane];
                 if constexpr (BORDER) {
 #pragma unroll
-                    for (int fb = 0; fb < NFB; ++fb) bacc[fb] += in[(NT * 4 + NFB + fb) * 64 + lane];
-                    cacc += in[(NT * 4 + 2 * NFB) * 64 + lane];
-                    eacc += in[(NT * 4 + 2 * NFB + 1) * 64 + lane];
+                    for (int fb = 0; fb < NFB; ++fb) bacc[fb] += vi[(NFB + fb) * 64 + lane];
+                    cacc += vi[2 * NFB * 64 + lane];
+                    eacc += vi[(2 * NFB + 1) * 64 + lane];
                 }
             }
         }
@@ -384,7 +413,7 @@ static bool dw_border(int f) { return f > 16 && f % 16 == 1 && (f / 16) % 4 != 3
 int64_t wmf_directw_partial_floats(int f) {
     if (f < 1 || f > 144) return 0;
     const int64_t nfb = dw_border(f) ? f / 16 : (f + 15) / 16;
-    return (nfb * (nfb + 1) / 2 * 4 + nfb + (dw_border(f) ? nfb + 2 : 0)) * 64;
+    return nfb * (nfb - 1) / 2 * 256 + nfb * WMF_DW_TRI + (nfb + (dw_border(f) ? nfb + 2 : 0)) * 64;
 }
 
 int wmf_launch_accumulate(const float* V, const int64_t* indptr, const int32_t* degrees, const int32_t* indices,
