@@ -56,6 +56,9 @@
 #ifndef WMF_DW_OCC4
 #define WMF_DW_OCC4 3
 #endif
+#ifndef WMF_DW_OPAQUE
+#define WMF_DW_OPAQUE 1
+#endif
 #ifndef WMF_DW_GJ_LDS
 #define WMF_DW_GJ_LDS -1          // multiplier column of the tile inverse: 1 = ds_bpermute, 0 = two VALU lane swaps, -1 = by occupancy
 #endif
@@ -263,7 +266,16 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
             for (int p = 0; p < NFB; ++p) {
                 f32x4 X = acc[tile_w<NFB>(p, p)];
                 constexpr bool GJ_LDS = WMF_DW_GJ_LDS < 0 ? (DwCfg<NFB>::OCC > 1) : (WMF_DW_GJ_LDS != 0);
+#if WMF_DW_OPAQUE
+                // the sweep's lane masks (r == K, q == K / 4) are the same for every pivot; hipcc hoists all 36 of them out of
+                // the pivot loop and then spills them to VGPR lanes (v_writelane / v_readlane pairs around every use).  Lane
+                // ids the compiler cannot see through make it compare in place: 20 v_cmp per pivot instead.
+                int rp = r, qp = q;
+                asm volatile("" : "+v"(rp), "+v"(qp));
+                gj_inv_sweep<GJ_LDS, true>(X, baddr, rp, qp, ok, std::make_integer_sequence<int, 16>{});
+#else
                 gj_inv_sweep<GJ_LDS, true>(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
+#endif
                 // y_p[r] complete (its four q shares added), then w_p = X y_p: lane (r, q) has X[4q + reg][r] (X is
                 // symmetric), so the products summed over the 16 lanes of a DPP row give w_p[4q + reg] on the whole row
                 float yp = racc[p];
