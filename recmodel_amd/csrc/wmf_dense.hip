@@ -627,37 +627,56 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
     const int lane = tid & 63, wv = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int nch = ld >> 2;
-    for (int64_t blk = (int64_t)blockIdx.x * 8 + wv; blk < nblocks16; blk += (int64_t)gridDim.x * 8) {
+    // per k block t: which output blocks have a non-zero tile of W (wave-uniform bit mask, kept in SGPRs)
+    unsigned tmask[NFB];
+#pragma unroll
+    for (int t = 0; t < NFB; ++t) {
+        unsigned mk = 0;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) mk |= nz[t * NBW + nb] ? (1u << nb) : 0u;
+        tmask[t] = __builtin_amdgcn_readfirstlane(mk);
+    }
+    // A whole 16-row block (all NFB pieces of a lane's row) is requested at once, and the NEXT block of this wave is
+    // requested before the MFMAs of the current one start: 2 x NFB 16-byte loads in flight per lane.  (One piece ahead,
+    // as before, left a 10 M x 132 transform at 2.8 TB/s: two 1 KB wave loads in flight per wave hide no HBM latency.)
+    // Beyond NFB = 11 (the column-sliced launches for f > 176) two blocks of pieces no longer fit the 256 registers of a
+    // wave at two waves per SIMD: one block at a time there, all its pieces requested together.
+    constexpr bool DBL = NFB <= 11;
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    auto request = [&](int64_t blk, float4 (&x)[NFB]) {
+        const int64_t row = blk * 16 + r;
+        const float4* irow = reinterpret_cast<const float4*>(in + (row < m ? row : 0) * (int64_t)ld);   // loads are unconditional
+#pragma unroll
+        for (int t = 0; t < NFB; ++t) x[t] = irow[min(4 * t + q, nch - 1)];
+    };
+    auto block = [&](int64_t blk, float4 (&xc)[NFB], float4 (&xn)[NFB]) {
+        if constexpr (DBL) { if (blk + stride < nblocks16) request(blk + stride, xn); }
         const int64_t row = blk * 16 + r;
         const bool rok = row < m;
-        const float4* irow = reinterpret_cast<const float4*>(in + (rok ? row : 0) * (int64_t)ld);   // loads are unconditional
         f32x4 acc[NBW];
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float4 xn = irow[min(q, nch - 1)];
-        if (!(rok && q < nch)) xn = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 1
+#pragma unroll
         for (int t = 0; t < NFB; ++t) {
             const int c = 4 * t + q;                 // 16-byte piece index within the row
-            const float4 x = xn;
-            if (t + 1 < NFB) {                       // prefetch the next piece
-                xn = irow[min(c + 4, nch - 1)];
-                if (!(rok && c + 4 < nch)) xn = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
             const int k0 = 4 * c;
-            int tnz[NBW];
+            // Rows past m compute garbage that is never stored (row r of A only reaches output row r), and every piece but
+            // the last lies inside the f features, so only the last piece is masked (its load was clamped).
+            float xe[4] = {xc[t].x, xc[t].y, xc[t].z, xc[t].w};
+            if (t == NFB - 1) {
 #pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) tnz[nb] = __builtin_amdgcn_readfirstlane(nz[t * NBW + nb]);
-            float xe[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (k0 + e >= f) xe[e] = 0.f;
-            if (set_col0_one && c == 0) {
-                if (rok && col0_out && NB0 == 0) col0_out[row] = xe[0];
-                xe[0] = rok ? 1.f : 0.f;
+                for (int e = 0; e < 4; ++e) if (!(c < nch && k0 + e < f)) xe[e] = 0.f;
             }
+            if (t == 0 && set_col0_one && q == 0) {
+                if (rok && col0_out && NB0 == 0) col0_out[row] = xe[0];
+                xe[0] = 1.f;
+            }
+            unsigned mv = tmask[t];
+            asm volatile("" : "+v"(mv));                     // test the bits here: hoisted, the 81 branch conditions spill
+            const unsigned mk = __builtin_amdgcn_readfirstlane(mv);
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
-                if (!tnz[nb]) continue;                      // wave-uniform: an all-zero tile of W
+                if (!(mk & (1u << nb))) continue;            // wave-uniform: an all-zero tile of W
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int k = k0 + e;
@@ -684,6 +703,24 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
                     if (col < ld) o[col] = acc[nb][reg];
                 }
             }
+        }
+    };
+    int64_t blk = (int64_t)blockIdx.x * 8 + wv;
+    if constexpr (DBL) {
+        float4 xa[NFB], xb[NFB];
+        if (blk < nblocks16) request(blk, xa);
+        while (blk < nblocks16) {
+            block(blk, xa, xb);
+            blk += stride;
+            if (blk >= nblocks16) break;
+            block(blk, xb, xa);
+            blk += stride;
+        }
+    } else {
+        float4 xa[NFB];
+        for (; blk < nblocks16; blk += stride) {
+            request(blk, xa);
+            block(blk, xa, xa);
         }
     }
 }
