@@ -34,8 +34,8 @@ SOLVE_BINS = {4: 0, 5: 1, 11: 2, 6: 3}   # profile slot -> plan bin whose rows t
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=sorted(synth.CONFIGS))
     ap.add_argument("--zipf", type=float, default=0.0, help="item popularity exponent (0 = uniform)")
     ap.add_argument("--chunks", type=int, default=0,
@@ -297,7 +297,7 @@ def main():
         "row_bins": {s: {"rows": eng.csr[s].bin_rows.tolist(), "nnz": eng.csr[s].bin_nnz.tolist()} for s in ("users", "items")},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        su = args.cpu_users or {64: 100_000, 128: 30_000, 16: 943, 256: 8_000}.get(k, 20_000)
+        su = args.cpu_users or {64: 300_000, 128: 60_000, 16: 943, 256: 12_000}.get(k, 20_000)
         su = min(su, n_users_1)
         si = max(1, min(n_items, su * n_items // n_users_1))
         ip = indptr[: su + 1].cpu().numpy()
