@@ -31,6 +31,7 @@
 #include "wmf_common.h"
 #include "wmf_internal.h"
 #include "wmf_stream.h"
+#include "wmf_dw_elim.h"
 
 #include <type_traits>
 
@@ -56,9 +57,6 @@
 #ifndef WMF_DW_OCC4
 #define WMF_DW_OCC4 3
 #endif
-#ifndef WMF_DW_OPAQUE
-#define WMF_DW_OPAQUE 1
-#endif
 #ifndef WMF_DW_GJ_LDS
 #define WMF_DW_GJ_LDS -1          // multiplier column of the tile inverse: 1 = ds_bpermute, 0 = two VALU lane swaps, -1 = by occupancy
 #endif
@@ -69,10 +67,6 @@ struct DwCfg {
     static constexpr int OCC = NFB <= 4 ? WMF_DW_OCC4 : (NFB <= 6 ? 2 : (NFB <= 8 ? WMF_DW_OCC8 : 1));      // waves per SIMD
 };
 
-template <int NFB>
-__device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for bj = bi .. NFB - 1"
-    return bi * NFB - (bi * (bi - 1)) / 2 + (bj - bi);
-}
 
 // MODE 0: one wave per row (accumulate + eliminate).
 // Rows with more than WMF_HEAVY_T entries are split (power-law degrees):
@@ -254,110 +248,13 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
             }
         }
 
-        // ---- C: block elimination, everything in registers except the two panel buffers
+        // ---- C, D: block elimination and backward pass (wmf_dw_elim.h)
         bool ok = true;
-        if (!(dbg & 1)) {
-#pragma unroll
-            for (int b = 0; b < NFB; ++b) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) if (r == 4 * q + reg) acc[tile_w<NFB>(b, b)][reg] += 1.f;
-            }
-#pragma unroll
-            for (int p = 0; p < NFB; ++p) {
-                f32x4 X = acc[tile_w<NFB>(p, p)];
-                constexpr bool GJ_LDS = WMF_DW_GJ_LDS < 0 ? (DwCfg<NFB>::OCC > 1) : (WMF_DW_GJ_LDS != 0);
-#if WMF_DW_OPAQUE
-                // the sweep's lane masks (r == K, q == K / 4) are the same for every pivot; hipcc hoists all 36 of them out of
-                // the pivot loop and then spills them to VGPR lanes (v_writelane / v_readlane pairs around every use).  Lane
-                // ids the compiler cannot see through make it compare in place: 20 v_cmp per pivot instead.
-                int rp = r, qp = q;
-                asm volatile("" : "+v"(rp), "+v"(qp));
-                gj_inv_sweep<GJ_LDS, true>(X, baddr, rp, qp, ok, std::make_integer_sequence<int, 16>{});
-#else
-                gj_inv_sweep<GJ_LDS, true>(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
-#endif
-                // y_p[r] complete (its four q shares added), then w_p = X y_p: lane (r, q) has X[4q + reg][r] (X is
-                // symmetric), so the products summed over the 16 lanes of a DPP row give w_p[4q + reg] on the whole row
-                float yp = racc[p];
-                yp += __shfl_xor(yp, 16);
-                yp += __shfl_xor(yp, 32);
-                float wv0 = X[0] * yp, wv1 = X[1] * yp, wv2 = X[2] * yp, wv3 = X[3] * yp;
-                wmf_row16_sum4(wv0, wv1, wv2, wv3);
-                if (r == 0) *reinterpret_cast<float4*>(&Wv[16 * p + 4 * q]) = make_float4(wv0, wv1, wv2, wv3);
-                float wb0 = 0.f, wb1 = 0.f, wb2 = 0.f, wb3 = 0.f;
-                if constexpr (BORDER) {
-                    float bp = bacc[p];
-                    bp += __shfl_xor(bp, 16);
-                    bp += __shfl_xor(bp, 32);
-                    wb0 = X[0] * bp; wb1 = X[1] * bp; wb2 = X[2] * bp; wb3 = X[3] * bp;
-                    wmf_row16_sum4(wb0, wb1, wb2, wb3);
-                    if (r == 0) *reinterpret_cast<float4*>(&Wb[16 * p + 4 * q]) = make_float4(wb0, wb1, wb2, wb3);
-                    // b_p^T w^b_p and b_p^T w^y_p: this q group's rows 4q + reg (b_p[row] sits in lane `row`)
-                    const float b0 = __shfl(bp, 4 * q), b1 = __shfl(bp, 4 * q + 1), b2 = __shfl(bp, 4 * q + 2), b3 = __shfl(bp, 4 * q + 3);
-                    cacc -= b0 * wb0 + b1 * wb1 + b2 * wb2 + b3 * wb3;
-                    eacc -= b0 * wv0 + b1 * wv1 + b2 * wv2 + b3 * wv3;
-                }
-                // Row p: W_pj = X B_pj replaces the tile, the original goes to `orig` for the trailing update.  Both operands
-                // of that update are elements THIS lane already holds: instruction e of  B_ij -= B_pi^T W_pj  wants
-                // A[m = r][k = q] = B_pi[4q + e][r] and B[k = q][n = r] = W_pj[4q + e][r], i.e. register e of the two tiles in
-                // accumulator layout -- no LDS panel, no exchange.
-                f32x4 orig[NFB];
-#pragma unroll
-                for (int j = p + 1; j < NFB; ++j) {
-                    const int t = tile_w<NFB>(p, j);
-                    orig[j] = acc[t];
-                    f32x4 n = f32x4{0.f, 0.f, 0.f, 0.f};
-                    n = WMF_MFMA16(X[0], acc[t][0], n); n = WMF_MFMA16(X[1], acc[t][1], n);
-                    n = WMF_MFMA16(X[2], acc[t][2], n); n = WMF_MFMA16(X[3], acc[t][3], n);
-                    acc[t] = n;                                  // W_pj stays in registers for the backward pass too
-                }
-#pragma unroll
-                for (int i = p + 1; i < NFB; ++i) {
-                    float a[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] = -orig[i][e];
-                    // y_i[r] -= sum_rows B_pi[row][r] w_p[row]: this lane's rows are 4q + e, a[e] = -B_pi[4q + e][r]
-                    racc[i] += a[0] * wv0 + a[1] * wv1 + a[2] * wv2 + a[3] * wv3;
-                    if constexpr (BORDER) bacc[i] += a[0] * wb0 + a[1] * wb1 + a[2] * wb2 + a[3] * wb3;
-#pragma unroll
-                    for (int j = i; j < NFB; ++j) {
-                        const int t = tile_w<NFB>(i, j), tw = tile_w<NFB>(p, j);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[t] = WMF_MFMA16(a[e], acc[tw][e], acc[t]);
-                    }
-                }
-            }
-        }
-        // ---- D: g_p = w_p - sum_{j > p} W_pj g_j ; gb[j] = g_j[lane & 15] on every lane
         float gb[NFB];
-        float tb = 0.f;                                          // BORDER: the last unknown
-        if constexpr (BORDER) {
-            cacc += __shfl_xor(cacc, 16); cacc += __shfl_xor(cacc, 32);
-            eacc += __shfl_xor(eacc, 16); eacc += __shfl_xor(eacc, 32);
-            const float piv = 1.f + cacc;                       // identity + c - sum_p b_p^T w^b_p
-            if (!(piv > 1e-20f)) ok = false;
-            tb = eacc * __builtin_amdgcn_rcpf(piv);
-        }
-        if (!(dbg & 1)) {
-#pragma unroll
-            for (int p = NFB - 1; p >= 0; --p) {
-                float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = p + 1; j < NFB; ++j) {
-                    const int t = tile_w<NFB>(p, j);
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) s[reg] += acc[t][reg] * gb[j];
-                }
-                float gsel = 0.f;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    float w = Wv[16 * p + 4 * q + reg];                                   // w_p[4q + reg]
-                    if constexpr (BORDER) w -= tb * Wb[16 * p + 4 * q + reg];
-                    const float gv = w - ((p + 1 < NFB) ? wmf_row16_sum(s[reg]) : 0.f);  // g_p[4q + reg] on every lane (., q)
-                    gsel = ((r & 3) == reg) ? gv : gsel;
-                }
-                gb[p] = __shfl(gsel, 16 * (r >> 2) + (r & 3)); // g_p[r] sits in q-group r >> 2, in a lane whose r & 3 matches
-            }
+        float tb = 0.f;
+        {
+            constexpr bool GJ_LDS = WMF_DW_GJ_LDS < 0 ? (DwCfg<NFB>::OCC > 1) : (WMF_DW_GJ_LDS != 0);
+            dw_eliminate<NFB, BORDER, GJ_LDS>(acc, racc, bacc, cacc, eacc, Wv, Wb, r, q, baddr, dbg, gb, tb, ok);
         }
         if (!ok) {
             if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;
@@ -385,7 +282,10 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
     const int64_t cap = 256 * waves_per_cu * 3;                  // resident waves, three rounds queued
     const int32_t* rows = pl->rows[WMF_BIN_MFMA];
     const int64_t normal = pl->count[WMF_BIN_MFMA] - pl->heavy_count;
-    if (normal > 0)
+    // k = 128 with or without biases: the LDS-DMA ring kernel (wmf_directl.hip); debug flag 4096 keeps the register ring
+    if (normal > 0 && biasv == nullptr && wmf_directl_supported(f, ld) && !(dbg & 4096)) {
+        (void)wmf_launch_directl(rows, normal, V, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, st);
+    } else if (normal > 0)
         hipLaunchKernelGGL((solve_directw_kernel<NFB, 0, BORDER>), dim3((unsigned)(normal < cap ? normal : cap)), dim3(64), 0, st,
                            rows, normal, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
                            nullptr, nullptr, nullptr, nullptr, 1, 0);

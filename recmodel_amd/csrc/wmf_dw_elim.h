@@ -1,0 +1,142 @@
+// Block LDL^T elimination of the whitened f x f system held in MFMA accumulator tiles (phases C and D of the
+// one-wave-per-row heavy-row kernels; see the header comment of wmf_directw.hip for the algebra and the layouts).
+// In:  acc[tile_w(bi, bj)] = tile (bi, bj), bi <= bj, of V_u^T D V_u (the identity is added here); racc[fb] = this
+//      lane's share (its q) of (V_u^T p)[16 fb + r]; BORDER: bacc / cacc / eacc = border column, corner, border rhs.
+// Out: gb[p] = g[16 p + (lane & 15)] on every lane, tb = the border unknown, ok = false if a pivot was not positive.
+// Wv / Wb: two LDS vectors of NFB * 16 floats owned by this wave.  NOT __restrict__: lanes r == 0 write them under an exec
+// mask and every lane reads them back; told that nothing else touches the memory, hipcc turns the masked store into
+// load - select - store by ALL lanes, and the lanes that share an address then race with the one real writer.
+#pragma once
+#include "wmf_common.h"
+
+template <int NFB>
+__device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for bj = bi .. NFB - 1"
+    return bi * NFB - (bi * (bi - 1)) / 2 + (bj - bi);
+}
+
+#ifndef WMF_DW_OPAQUE
+#define WMF_DW_OPAQUE 1
+#endif
+
+// WREG: w_p (and w^b_p) stay in registers instead of the two LDS vectors -- after the DPP row sums every lane (., q) holds
+// w_p[4q + reg] already, which is all the backward pass reads (used by the LDS-DMA kernel, which keeps LDS accesses that the
+// compiler can see out of the kernel).
+template <int NFB, bool BORDER, bool GJ_LDS, bool WREG = false>
+__device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], float (&racc)[NFB], float (&bacc)[BORDER ? NFB : 1],
+                                             float& cacc, float& eacc, float* Wv, float* Wb, int r,
+                                             int q, const int (&baddr)[4], int dbg, float (&gb)[NFB], float& tb, bool& ok) {
+    float wvs[WREG ? NFB : 1][4], wbs[(WREG && BORDER) ? NFB : 1][4];
+    // ---- C: block elimination, everything in registers except the two panel buffers
+    if (!(dbg & 1)) {
+#pragma unroll
+        for (int b = 0; b < NFB; ++b) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) if (r == 4 * q + reg) acc[tile_w<NFB>(b, b)][reg] += 1.f;
+        }
+#pragma unroll
+        for (int p = 0; p < NFB; ++p) {
+            f32x4 X = acc[tile_w<NFB>(p, p)];
+#if WMF_DW_OPAQUE
+            // the sweep's lane masks (r == K, q == K / 4) are the same for every pivot; hipcc hoists all 36 of them out of
+            // the pivot loop and then spills them to VGPR lanes (v_writelane / v_readlane pairs around every use).  Lane
+            // ids the compiler cannot see through make it compare in place: 20 v_cmp per pivot instead.
+            int rp = r, qp = q;
+            asm volatile("" : "+v"(rp), "+v"(qp));
+            gj_inv_sweep<GJ_LDS, true>(X, baddr, rp, qp, ok, std::make_integer_sequence<int, 16>{});
+#else
+            gj_inv_sweep<GJ_LDS, true>(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
+#endif
+            // y_p[r] complete (its four q shares added), then w_p = X y_p: lane (r, q) has X[4q + reg][r] (X is
+            // symmetric), so the products summed over the 16 lanes of a DPP row give w_p[4q + reg] on the whole row
+            float yp = racc[p];
+            yp += __shfl_xor(yp, 16);
+            yp += __shfl_xor(yp, 32);
+            float wv0 = X[0] * yp, wv1 = X[1] * yp, wv2 = X[2] * yp, wv3 = X[3] * yp;
+            wmf_row16_sum4(wv0, wv1, wv2, wv3);
+            if constexpr (WREG) { wvs[p][0] = wv0; wvs[p][1] = wv1; wvs[p][2] = wv2; wvs[p][3] = wv3; }
+            else if (r == 0) *reinterpret_cast<float4*>(&Wv[16 * p + 4 * q]) = make_float4(wv0, wv1, wv2, wv3);
+            float wb0 = 0.f, wb1 = 0.f, wb2 = 0.f, wb3 = 0.f;
+            if constexpr (BORDER) {
+                float bp = bacc[p];
+                bp += __shfl_xor(bp, 16);
+                bp += __shfl_xor(bp, 32);
+                wb0 = X[0] * bp; wb1 = X[1] * bp; wb2 = X[2] * bp; wb3 = X[3] * bp;
+                wmf_row16_sum4(wb0, wb1, wb2, wb3);
+                if constexpr (WREG) { wbs[p][0] = wb0; wbs[p][1] = wb1; wbs[p][2] = wb2; wbs[p][3] = wb3; }
+                else if (r == 0) *reinterpret_cast<float4*>(&Wb[16 * p + 4 * q]) = make_float4(wb0, wb1, wb2, wb3);
+                // b_p^T w^b_p and b_p^T w^y_p: this q group's rows 4q + reg (b_p[row] sits in lane `row`)
+                const float b0 = __shfl(bp, 4 * q), b1 = __shfl(bp, 4 * q + 1), b2 = __shfl(bp, 4 * q + 2), b3 = __shfl(bp, 4 * q + 3);
+                cacc -= b0 * wb0 + b1 * wb1 + b2 * wb2 + b3 * wb3;
+                eacc -= b0 * wv0 + b1 * wv1 + b2 * wv2 + b3 * wv3;
+            }
+            // Row p: W_pj = X B_pj replaces the tile, the original goes to `orig` for the trailing update.  Both operands
+            // of that update are elements THIS lane already holds: instruction e of  B_ij -= B_pi^T W_pj  wants
+            // A[m = r][k = q] = B_pi[4q + e][r] and B[k = q][n = r] = W_pj[4q + e][r], i.e. register e of the two tiles in
+            // accumulator layout -- no LDS panel, no exchange.
+            f32x4 orig[NFB];
+#pragma unroll
+            for (int j = p + 1; j < NFB; ++j) {
+                const int t = tile_w<NFB>(p, j);
+                orig[j] = acc[t];
+                f32x4 n = f32x4{0.f, 0.f, 0.f, 0.f};
+                n = WMF_MFMA16(X[0], acc[t][0], n); n = WMF_MFMA16(X[1], acc[t][1], n);
+                n = WMF_MFMA16(X[2], acc[t][2], n); n = WMF_MFMA16(X[3], acc[t][3], n);
+                acc[t] = n;                                  // W_pj stays in registers for the backward pass too
+            }
+#pragma unroll
+            for (int i = p + 1; i < NFB; ++i) {
+                float a[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = -orig[i][e];
+                // y_i[r] -= sum_rows B_pi[row][r] w_p[row]: this lane's rows are 4q + e, a[e] = -B_pi[4q + e][r]
+                racc[i] += a[0] * wv0 + a[1] * wv1 + a[2] * wv2 + a[3] * wv3;
+                if constexpr (BORDER) bacc[i] += a[0] * wb0 + a[1] * wb1 + a[2] * wb2 + a[3] * wb3;
+#pragma unroll
+                for (int j = i; j < NFB; ++j) {
+                    const int t = tile_w<NFB>(i, j), tw = tile_w<NFB>(p, j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t] = WMF_MFMA16(a[e], acc[tw][e], acc[t]);
+                }
+            }
+        }
+    }
+    // The backward pass reads what OTHER lanes (r == 0) stored into Wv / Wb above.  Per thread nothing orders a lane's load
+    // after another lane's store, and hipcc did move the last pivot's load above the store for the lanes that do not
+    // write; the wave-scope fence pair and the scheduling barrier pin the order the wave's lockstep execution relies on.
+    if constexpr (!WREG) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // ---- D: g_p = w_p - sum_{j > p} W_pj g_j ; gb[j] = g_j[lane & 15] on every lane
+    tb = 0.f;                                                // BORDER: the last unknown
+    if constexpr (BORDER) {
+        cacc += __shfl_xor(cacc, 16); cacc += __shfl_xor(cacc, 32);
+        eacc += __shfl_xor(eacc, 16); eacc += __shfl_xor(eacc, 32);
+        const float piv = 1.f + cacc;                       // identity + c - sum_p b_p^T w^b_p
+        if (!(piv > 1e-20f)) ok = false;
+        tb = eacc * __builtin_amdgcn_rcpf(piv);
+    }
+    if (!(dbg & 1)) {
+#pragma unroll
+        for (int p = NFB - 1; p >= 0; --p) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = p + 1; j < NFB; ++j) {
+                const int t = tile_w<NFB>(p, j);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) s[reg] += acc[t][reg] * gb[j];
+            }
+            float gsel = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float w;                                                              // w_p[4q + reg]
+                if constexpr (WREG) { w = wvs[p][reg]; if constexpr (BORDER) w -= tb * wbs[p][reg]; }
+                else { w = Wv[16 * p + 4 * q + reg]; if constexpr (BORDER) w -= tb * Wb[16 * p + 4 * q + reg]; }
+                const float gv = w - ((p + 1 < NFB) ? wmf_row16_sum(s[reg]) : 0.f);  // g_p[4q + reg] on every lane (., q)
+                gsel = ((r & 3) == reg) ? gv : gsel;
+            }
+            gb[p] = __shfl(gsel, 16 * (r >> 2) + (r & 3)); // g_p[r] sits in q-group r >> 2, in a lane whose r & 3 matches
+        }
+    }
+}

@@ -48,6 +48,10 @@ int wmf_direct_supported(int f);
 int wmf_launch_direct(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
                       int32_t* fb_count, hipStream_t st);
+// wmf_directl.hip: normal heavy rows at f = 128 / 129 through an LDS-DMA row ring
+int wmf_directl_supported(int f, int ld);
+int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const int64_t* indptr, const int32_t* indices,
+                       const float* vals, int f, int ld, float* g, int32_t* fb_rows, int32_t* fb_count, hipStream_t st);
 int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int f, int ld, float* g, hipStream_t st);
 int64_t wmf_directw_partial_floats(int f);
