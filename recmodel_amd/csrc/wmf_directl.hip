@@ -12,10 +12,9 @@
 //   metadata  indices / weights of block b go to LDS by two dword DMAs (lane l = entry 64 b + l), one block ahead;
 //             the border feature V[idx][128] (f = 129) by a third one once the indices have landed.
 //   rows      DMA instruction i of group g fetches 32 pieces of 16 bytes (features 0..127) of two rows into
-//             slot[g % 4] + 1024 i: lanes 0..31 row A, lanes 32..63 row B, so that no instruction's kilobyte crosses a
-//             row.  Ring position P = 2 i + h holds CSR entry 8 h + i of the group (h = lane >> 5): a lane then needs the
-//             indices of eight CONSECUTIVE entries, two ds_read_b128.
-//   consume   k-step t takes ring positions 4 t + q; lane (r, q) reads pieces r and r + 16 of its row (the feature
+//             slot[g % 4] + 1024 i: lanes 0..31 entry 2 i, lanes 32..63 entry 2 i + 1, so that no instruction's kilobyte
+//             crosses a row; a lane half h = lane >> 5 needs the indices of entries h, 2 + h, .. 14 + h: four ds_read2_b32.
+//   consume   k-step t takes entries 4 t + q (k-steps past the row's end are skipped); lane (r, q) reads pieces r and r + 16 of its row (the feature
 //             permutation of wmf_stream.h: virtual block 4 j + e = feature 64 j + 4 r + e), its weight and its border value.
 // Everything hipcc must not see is inline asm: while an LDS-DMA is in flight the compiler waits vmcnt(0) before any LDS
 // read or use of an ordinary load it knows of, which would drain the ring.  The waits are counted by hand (vmcnt is in
@@ -28,6 +27,9 @@
 #include <utility>
 
 #define DL_NFB 8
+#ifndef DL_GJ_LDS
+#define DL_GJ_LDS 0                 // multiplier column of the tile inverse: 1 = ds_bpermute, 0 = two VALU lane swaps
+#endif
 #define DL_R 4                      // ring slots = groups per 64-entry block (the group loop is unrolled by it)
 #define DL_SLOT 8192                // bytes: 16 rows x 512
 #define DL_META (DL_R * DL_SLOT)    // idx[4][64], w[4][64], border[4][64] behind the ring: metadata of block b in buffer b & 3
@@ -50,6 +52,13 @@ __device__ __forceinline__ float dl_read32(unsigned addr) {
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int OFF0, int OFF1>
+__device__ __forceinline__ f32x2 dl_read2(unsigned addr) {       // dwords at addr + 4 OFF0 and addr + 4 OFF1
+    f32x2 v;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(OFF0), "n"(OFF1) : "memory");
+    return v;
+}
 template <int N>
 __device__ __forceinline__ void dl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -68,24 +77,26 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
     for (int kq = 0; kq < 4; ++kq) baddr[kq] = (r + 16 * kq) * 4;
     // LDS byte addresses of this lane's reads (inline asm below)
     const unsigned ring_rd = lds0 + q * 512 + r * 16;                              // + slot * 8192 + t * 2048 + j * 256
-    const unsigned meta_rd = lds0 + DL_META + (8 * (q & 1) + (q >> 1)) * 4;       // + (block & 3) * 256 + (group in block * 16 + 2 t) * 4
-    const unsigned idx8_rd = lds0 + DL_META + 8 * h * 4;                          // + (block & 3) * 256 + group in block * 64
+    const unsigned meta_rd = lds0 + DL_META + q * 4;                               // + (block & 3) * 256 + (group in block * 16 + 2 t) * 4
+    const unsigned idx8_rd = lds0 + DL_META + h * 4;                              // + (block & 3) * 256 + group in block * 64
     const int piece = (lane & 31) * 4;                                      // first float of this lane's piece
 
     auto item = [&](int64_t i, int& u_, int64_t& lo_, int& d_) {
         u_ = rows[i]; lo_ = indptr[u_]; d_ = (int)(indptr[u_ + 1] - lo_);
     };
     // metadata of block b of row (lo_, d_): lane l <- entry min(64 b + l, d_ - 1) (clamped entries get weight 0 at use)
-    auto issue_meta = [&](int b, int64_t lo_, int d_) {
+    // (metadata of block b of the row whose first block uses buffer `base`: buffer (base + b) & 3 -- the buffers rotate
+    // across rows, so that the next row's first block can be requested while this row's last one is still in use)
+    auto issue_meta = [&](int b, int64_t lo_, int d_, int base) {
         const int64_t e = lo_ + min(64 * b + lane, d_ - 1);
-        const unsigned par = (b & 3) * 256;
+        const unsigned par = ((base + b) & 3) * 256;
         __builtin_amdgcn_global_load_lds((dl_gptr)(indices + e), (dl_lptr)(smem + DL_META + par), 4, 0, 0);
         __builtin_amdgcn_global_load_lds((dl_gptr)(vals + e), (dl_lptr)(smem + DL_META + DL_W + par), 4, 0, 0);
     };
     // border feature of the entries of block b (its indices have landed)
-    auto issue_border = [&](int b) {
+    auto issue_border = [&](int b, int base) {
         if constexpr (BORDER) {
-            const unsigned par = (b & 3) * 256;
+            const unsigned par = ((base + b) & 3) * 256;
             float iv = dl_read32<0>(lds0 + DL_META + par + lane * 4);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(iv)::"memory");     // the value passes through the wait: no use can move above it
             const int idx = __builtin_bit_cast(int, iv);
@@ -93,12 +104,13 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
         }
     };
     // the 16 rows of group gi (S = gi % 4 = its ring slot and its position in the block) -> 8 DMA instructions
-    auto issue_rows = [&](auto slot, int gi) {
+    auto issue_rows = [&](auto slot, int gi, int base) {
         constexpr int S = decltype(slot)::value;
-        const unsigned par = ((gi >> 2) & 3) * 256;
-        f32x4 ia = dl_read128<S * 64>(idx8_rd + par), ib = dl_read128<S * 64 + 16>(idx8_rd + par);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ia), "+v"(ib)::"memory");
-        const float ids[8] = {ia[0], ia[1], ia[2], ia[3], ib[0], ib[1], ib[2], ib[3]};
+        const unsigned par = ((base + (gi >> 2)) & 3) * 256;
+        f32x2 i0 = dl_read2<S * 16, S * 16 + 2>(idx8_rd + par), i1 = dl_read2<S * 16 + 4, S * 16 + 6>(idx8_rd + par);
+        f32x2 i2 = dl_read2<S * 16 + 8, S * 16 + 10>(idx8_rd + par), i3 = dl_read2<S * 16 + 12, S * 16 + 14>(idx8_rd + par);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3)::"memory");
+        const float ids[8] = {i0[0], i0[1], i1[0], i1[1], i2[0], i2[1], i3[0], i3[1]};      // entries 2 i + h, i = 0 .. 7
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = __builtin_bit_cast(int, ids[i]);
@@ -111,24 +123,26 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
     int64_t it = blockIdx.x;
     // first requests of a row: metadata of block 0 (and 1), border of block 0, groups 0 .. 2.  Nothing else of this wave
     // is in flight when this runs, so the vmcnt(0) in it waits for the row's own first metadata only.
-    auto prime = [&](int64_t lo_, int d_) {
+    auto prime = [&](int64_t lo_, int d_, int base, bool meta0_requested) {
         const int ng = (d_ + 15) >> 4;
-        issue_meta(0, lo_, d_);
+        if (!meta0_requested) issue_meta(0, lo_, d_, base);
         dl_wait_vm<0>();
-        issue_border(0);
-        if (d_ > 64) issue_meta(1, lo_, d_);
-        issue_rows(std::integral_constant<int, 0>{}, 0);
-        if (ng > 1) issue_rows(std::integral_constant<int, 1>{}, 1);
-        if (ng > 2) issue_rows(std::integral_constant<int, 2>{}, 2);
+        issue_border(0, base);
+        if (d_ > 64) issue_meta(1, lo_, d_, base);
+        issue_rows(std::integral_constant<int, 0>{}, 0, base);
+        if (ng > 1) issue_rows(std::integral_constant<int, 1>{}, 1, base);
+        if (ng > 2) issue_rows(std::integral_constant<int, 2>{}, 2, base);
     };
-    if (it < count) { item(it, u, lo, d); prime(lo, d); }
+    int mb = 0;                                         // metadata buffer of the current row's block 0
+    if (it < count) { item(it, u, lo, d); prime(lo, d, mb, false); }
 
     for (; it < count; it += gridDim.x) {
         const int ngroups = (d + 15) >> 4;
         const int64_t itn = it + gridDim.x;
         int un = 0, dn = 0;
         int64_t lon = 0;
-        if (itn < count) item(itn, un, lon, dn);       // used in prime() below, when nothing is in flight any more
+        if (itn < count) item(itn, un, lon, dn);
+        const int mbn = (mb + ((ngroups + 3) >> 2)) & 3;   // metadata buffer of the next row's block 0
 
         f32x4 acc[NT];
 #pragma unroll
@@ -151,39 +165,55 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
                 if constexpr (SN == 0) {
                     // metadata of block gn / 4 was requested 32 operations ago (its own group requests and three more)
                     dl_wait_vm<32>();
-                    issue_border(gn >> 2);
-                    if (64 * ((gn >> 2) + 1) < d) issue_meta((gn >> 2) + 1, lo, d);
+                    issue_border(gn >> 2, mb);
+                    if (64 * ((gn >> 2) + 1) < d) issue_meta((gn >> 2) + 1, lo, d, mb);
                 }
-                issue_rows(std::integral_constant<int, SN>{}, gn);
+                issue_rows(std::integral_constant<int, SN>{}, gn, mb);
             }
+            // the row's last group: the NEXT row's first metadata block is requested now (its buffer, the one behind this
+            // row's last block, is free) and has a group of MFMAs to arrive before prime() waits for it
+            const bool last = G == ngroups - 1;
+            if (last && itn < count) issue_meta(0, lon, dn, mbn);
             // group G has landed when only the requests made after it are outstanding
             const int younger = min(3, ngroups - 1 - G);
             if (younger >= 3) dl_wait_vm<24>();
             else if (younger == 2) dl_wait_vm<16>();
             else if (younger == 1) dl_wait_vm<8>();
+            else if (itn < count) dl_wait_vm<2>();       // only the next row's two metadata requests are younger
             else dl_wait_vm<0>();
             if (dbg & 2) return;
-            const unsigned par = ((G >> 2) & 3) * 256;
-            auto kstep = [&](auto tc) {
+            const unsigned par = ((mb + (G >> 2)) & 3) * 256;
+            const int nk = min(4, (d - 16 * G + 3) >> 2);        // k-steps of this group that hold entries of the row
+            // LDS operands of k-step t + 1 are requested before the MFMAs of k-step t (only the first k-step of a group
+            // waits for its own reads with nothing to do)
+            f32x4 xa[2], xb[2];
+            float wv[2], bf[2] = {0.f, 0.f};
+            auto request = [&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                f32x4 xa = dl_read128<S * DL_SLOT + t * 2048>(ring_rd), xb = dl_read128<S * DL_SLOT + t * 2048 + 256>(ring_rd);
-                float wv = dl_read32<DL_W + (S * 16 + 2 * t) * 4>(meta_rd + par);
-                float bf = 0.f;
-                if constexpr (BORDER) bf = dl_read32<DL_BD + (S * 16 + 2 * t) * 4>(meta_rd + par);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa), "+v"(xb), "+v"(wv), "+v"(bf)::"memory");
-                // entry of ring position 4 t + q: 8 (P & 1) + (P >> 1), P & 1 = q & 1, P >> 1 = 2 t + (q >> 1)
-                const bool real = 16 * G + 8 * (q & 1) + 2 * t + (q >> 1) < d;
-                const float w = real ? wv : 0.f, p = real ? wv + 1.f : 0.f;
-                const float x[NFB] = {xa[0], xa[1], xa[2], xa[3], xb[0], xb[1], xb[2], xb[3]};
+                xa[t & 1] = dl_read128<S * DL_SLOT + t * 2048>(ring_rd);
+                xb[t & 1] = dl_read128<S * DL_SLOT + t * 2048 + 256>(ring_rd);
+                wv[t & 1] = dl_read32<DL_W + (S * 16 + 4 * t) * 4>(meta_rd + par);
+                if constexpr (BORDER) bf[t & 1] = dl_read32<DL_BD + (S * 16 + 4 * t) * 4>(meta_rd + par);
+            };
+            auto kstep = [&](auto tc) {
+                constexpr int t = decltype(tc)::value, B = t & 1;
+                if (t >= nk) return;                             // wave-uniform: past the row's end
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[B]), "+v"(xb[B]), "+v"(wv[B]), "+v"(bf[B])::"memory");
+                const f32x4 ya = xa[B], yb = xb[B];
+                const float wraw = wv[B], bfv = bf[B];
+                if constexpr (t < 3) { if (t + 1 < nk) request(std::integral_constant<int, t + 1>{}); }
+                const bool real = 16 * G + 4 * t + q < d;
+                const float w = real ? wraw : 0.f, p = real ? wraw + 1.f : 0.f;
+                const float x[NFB] = {ya[0], ya[1], ya[2], ya[3], yb[0], yb[1], yb[2], yb[3]};
                 float fw[NFB];
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) { fw[fb] = x[fb] * w; racc[fb] += x[fb] * p; }
                 if constexpr (BORDER) {
-                    const float bw = bf * w;
+                    const float bw = bfv * w;
 #pragma unroll
                     for (int fb = 0; fb < NFB; ++fb) bacc[fb] += x[fb] * bw;
-                    cacc += bf * bw;
-                    eacc += bf * p;
+                    cacc += bfv * bw;
+                    eacc += bfv * p;
                 }
                 int tt = 0;
 #pragma unroll
@@ -192,6 +222,7 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
                     for (int bj = bi; bj < NFB; ++bj, ++tt) acc[tt] = WMF_MFMA16(x[bi], fw[bj], acc[tt]);
                 }
             };
+            request(std::integral_constant<int, 0>{});
             [&]<int... Ts>(std::integer_sequence<int, Ts...>) {
                 (kstep(std::integral_constant<int, Ts>{}), ...);
             }(std::make_integer_sequence<int, 4>{});
@@ -201,13 +232,13 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
                 (step(std::integral_constant<int, Ss>{}, G0 + Ss), ...);
             }(std::make_integer_sequence<int, DL_R>{});
         }
-        if (itn < count) prime(lon, dn);                 // the next row's first 48 entries fly during the elimination
+        if (itn < count) prime(lon, dn, mbn, true);      // the next row's first 48 entries fly during the elimination
 
         // ---- C, D: block elimination and backward pass (wmf_dw_elim.h), w_p in registers
         bool ok = true;
         float gb[NFB];
         float tb = 0.f;
-        dw_eliminate<NFB, BORDER, false, true>(acc, racc, bacc, cacc, eacc, nullptr, nullptr, r, q, baddr, dbg, gb, tb, ok);
+        dw_eliminate<NFB, BORDER, (DL_GJ_LDS != 0), true>(acc, racc, bacc, cacc, eacc, nullptr, nullptr, r, q, baddr, dbg, gb, tb, ok);
         if (!ok) {
             if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;
         } else if (q == 0) {
@@ -221,7 +252,7 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
                 if (c < ld) g[(int64_t)u * ld + c] = (r == 0) ? tb : 0.f;
             }
         }
-        u = un; lo = lon; d = dn;
+        u = un; lo = lon; d = dn; mb = mbn;
     }
 }
 

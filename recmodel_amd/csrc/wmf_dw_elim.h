@@ -33,8 +33,10 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) if (r == 4 * q + reg) acc[tile_w<NFB>(b, b)][reg] += 1.f;
         }
-#pragma unroll
-        for (int p = 0; p < NFB; ++p) {
+        // LOOK-AHEAD: the inverse of pivot tile p + 1 is started as soon as row p + 1 of the trailing update has been
+        // applied, in front of the remaining rows' MFMAs, which it does not depend on: with one wave per SIMD nothing else
+        // hides the 16-step dependency chain of the Gauss-Jordan sweep.
+        auto invert = [&](int p) {
             f32x4 X = acc[tile_w<NFB>(p, p)];
 #if WMF_DW_OPAQUE
             // the sweep's lane masks (r == K, q == K / 4) are the same for every pivot; hipcc hoists all 36 of them out of
@@ -42,10 +44,17 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
             // ids the compiler cannot see through make it compare in place: 20 v_cmp per pivot instead.
             int rp = r, qp = q;
             asm volatile("" : "+v"(rp), "+v"(qp));
-            gj_inv_sweep<GJ_LDS, true>(X, baddr, rp, qp, ok, std::make_integer_sequence<int, 16>{});
+            if (!(dbg & 8))                                      // timing experiments only: 8 = no tile inverse
+                gj_inv_sweep<GJ_LDS, true>(X, baddr, rp, qp, ok, std::make_integer_sequence<int, 16>{});
 #else
             gj_inv_sweep<GJ_LDS, true>(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
 #endif
+            return X;
+        };
+        f32x4 Xnext = invert(0);
+#pragma unroll
+        for (int p = 0; p < NFB; ++p) {
+            const f32x4 X = Xnext;
             // y_p[r] complete (its four q shares added), then w_p = X y_p: lane (r, q) has X[4q + reg][r] (X is
             // symmetric), so the products summed over the 16 lanes of a DPP row give w_p[4q + reg] on the whole row
             float yp = racc[p];
@@ -97,6 +106,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[t] = WMF_MFMA16(a[e], acc[tw][e], acc[t]);
                 }
+                if (i == p + 1) Xnext = invert(p + 1);           // tile (p + 1, p + 1) is final: look ahead
             }
         }
     }

@@ -99,3 +99,15 @@ def test_no_oracle_import_in_product():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in text.replace("test infrastructure", ""), f"{fn} mentions the oracle"
+
+
+def test_lds_dma_kernel_leaves_in_flight_registers_alone():
+    """wmf_directl.hip reads its LDS ring with inline-asm ds_reads whose destination registers hipcc believes written at
+    once; nothing may touch them before the inline-asm wait that retires them (tools/check_inflight_regs.py parses the
+    gfx950 assembly of the file -- no GPU needed)."""
+    import subprocess
+    import sys
+    script = os.path.join(ROOT, "tools", "check_inflight_regs.py")
+    res = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "0 violations" in res.stdout
