@@ -62,7 +62,17 @@ __device__ __forceinline__ f32x2 dl_read2(unsigned addr) {       // dwords at ad
 template <int N>
 __device__ __forceinline__ void dl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool BORDER>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// X6: the accumulation B += V_u^T D V_u in split bf16 instead of f32 MFMAs.  Operands are scaled by sqrt(w) and split into
+// three bf16 parts x = hi + mid + lo (the split is exact: 3 x 8 significand bits); per tile and 32 entries six
+// v_mfma_f32_16x16x32_bf16 -- lo.hi, mid.mid, hi.lo, mid.hi, hi.mid, hi.hi, every product exact in f32, the dropped terms
+// below 2^-24 of the product -- replace eight v_mfma_f32_16x16x4_f32 at half the cycles each.  Accuracy of the accumulated
+// tile: 3.1e-7 relative against 2.2e-7 for f32 (tests/scale/proto_split.py: the half step's error is set by the fp32
+// whitening, not here).  A chunk = two ring slots = 32 entries; lane (r, q) takes entries 8 q .. 8 q + 7 of the chunk
+// (the K index of its MFMA operands).  A negative weight has no square root: the NaN it produces reaches the pivot test
+// and the row is bounced to the pivoted kernel, like every system that is not positive definite.
+template <bool BORDER, bool X6>
 __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __restrict__ rows, int64_t count, const float* __restrict__ V,
                                                               const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                               const float* __restrict__ vals, int f, int ld, float* __restrict__ g,
@@ -79,8 +89,20 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
     const unsigned ring_rd = lds0 + q * 512 + r * 16;                              // + slot * 8192 + t * 2048 + j * 256
     const unsigned meta_rd = lds0 + DL_META + q * 4;                               // + (block & 3) * 256 + (group in block * 16 + 2 t) * 4
     const unsigned idx8_rd = lds0 + DL_META + h * 4;                              // + (block & 3) * 256 + group in block * 64
+    const unsigned ring6_rd = lds0 + q * 4096 + r * 16;                     // X6: entries 8 q + j of a chunk: + slot * 8192 + j * 512 + piece * 256
+    const unsigned meta6_rd = lds0 + DL_META + q * 32;                     // X6: their eight weights / border values
     const int piece = (lane & 31) * 4;                                      // first float of this lane's piece
 
+    // The ring starts as zeros.  A chunk of the X6 path reads 32 ring positions even where the row has fewer entries left;
+    // those positions are cancelled by weight 0, which only works on finite data: after this, whatever is stale in the ring
+    // is an older row's real factor data, never an uninitialised bit pattern (a NaN there would send the row to the pivoted kernel).
+    {
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < DL_R * DL_SLOT / 1024; ++i)
+            asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + i * 1024 + lane * 16), "v"(z) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     auto item = [&](int64_t i, int& u_, int64_t& lo_, int& d_) {
         u_ = rows[i]; lo_ = indptr[u_]; d_ = (int)(indptr[u_ + 1] - lo_);
     };
@@ -132,6 +154,7 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
         issue_rows(std::integral_constant<int, 0>{}, 0, base);
         if (ng > 1) issue_rows(std::integral_constant<int, 1>{}, 1, base);
         if (ng > 2) issue_rows(std::integral_constant<int, 2>{}, 2, base);
+        if constexpr (X6) { if (ng > 3) issue_rows(std::integral_constant<int, 3>{}, 3, base); }     // two whole chunks
     };
     int mb = 0;                                         // metadata buffer of the current row's block 0
     if (it < count) { item(it, u, lo, d); prime(lo, d, mb, false); }
@@ -227,12 +250,111 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
                 (kstep(std::integral_constant<int, Ts>{}), ...);
             }(std::make_integer_sequence<int, 4>{});
         };
+        // ---- A (X6): one chunk = groups G, G + 1 = ring slots S, S + 1 (S = 0 or 2)
+        auto chunk = [&](auto slot, int G) {
+            constexpr int S = decltype(slot)::value;
+            if (G >= ngroups) return;
+            const bool lastc = G + 2 >= ngroups;                 // the row's last chunk
+            if (lastc && itn < count && !(dbg & 32768)) issue_meta(0, lon, dn, mbn);
+            // groups G, G + 1 have landed when only what was requested after them is outstanding: groups G + 2, G + 3
+            const int younger = max(0, min(2, ngroups - G - 2));
+            if (dbg & 16384) dl_wait_vm<0>();
+            else if (younger == 2) dl_wait_vm<16>();
+            else if (younger == 1) dl_wait_vm<8>();
+            else if (itn < count) dl_wait_vm<2>();
+            else dl_wait_vm<0>();
+            // all LDS operands of the chunk into registers: 8 entries x 2 pieces, their weights and border values
+            const unsigned par = ((mb + (G >> 2)) & 3) * 256;
+            f32x4 xr[8][2], wq[2], bq[2];
+            [&]<int... Js>(std::integer_sequence<int, Js...>) {
+                ((xr[Js][0] = dl_read128<S * DL_SLOT + Js * 512>(ring6_rd), xr[Js][1] = dl_read128<S * DL_SLOT + Js * 512 + 256>(ring6_rd)), ...);
+            }(std::make_integer_sequence<int, 8>{});
+            wq[0] = dl_read128<DL_W + S * 64>(meta6_rd + par);
+            wq[1] = dl_read128<DL_W + S * 64 + 16>(meta6_rd + par);
+            if constexpr (BORDER) {
+                bq[0] = dl_read128<DL_BD + S * 64>(meta6_rd + par);
+                bq[1] = dl_read128<DL_BD + S * 64 + 16>(meta6_rd + par);
+            } else {
+                bq[0] = bq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(xr[0][0]), "+v"(xr[0][1]), "+v"(xr[1][0]), "+v"(xr[1][1]), "+v"(xr[2][0]), "+v"(xr[2][1]), "+v"(xr[3][0]),
+                           "+v"(xr[3][1]), "+v"(xr[4][0]), "+v"(xr[4][1]), "+v"(xr[5][0]), "+v"(xr[5][1]), "+v"(xr[6][0]), "+v"(xr[6][1]),
+                           "+v"(xr[7][0]), "+v"(xr[7][1]), "+v"(wq[0]), "+v"(wq[1]), "+v"(bq[0]), "+v"(bq[1])::"memory");
+            // the two slots are free again: request groups G + 4, G + 5 into them (the first of them opens a block when S == 0)
+            if (G + 4 < ngroups) {
+                if constexpr (S == 0) {
+                    issue_border((G >> 2) + 1, mb);              // its indices are older than the groups just waited for
+                } else {
+                    if (64 * ((G >> 2) + 2) < d) issue_meta((G >> 2) + 2, lo, d, mb);    // two blocks on: needed in the next trip
+                }
+                issue_rows(std::integral_constant<int, S>{}, G + 4, mb);
+                if (G + 5 < ngroups) issue_rows(std::integral_constant<int, S + 1>{}, G + 5, mb);
+            }
+            if (dbg & 2) return;
+            // right-hand side and border on the VALU from the raw values; MFMA operands scaled by sqrt(w) and split.
+            // Block column by block column: the split of column bj + 1 (VALU) has no dependence on the MFMAs of column bj,
+            // and a bf16 MFMA leaves half of its cycles to the VALU.
+            float wj[8], pj[8], swj[8], bwj[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool real = 16 * G + 8 * q + j < d;
+                const float wraw = wq[j >> 2][j & 3];
+                wj[j] = real ? wraw : 0.f;
+                pj[j] = real ? wraw + 1.f : 0.f;
+                swj[j] = __builtin_amdgcn_sqrtf(wj[j]);
+                const float bfv = bq[j >> 2][j & 3];
+                bwj[j] = bfv * wj[j];
+                if constexpr (BORDER) { cacc += bfv * bwj[j]; eacc += bfv * pj[j]; }
+            }
+            bf16x8 hi[NFB], mid[NFB], lo3[NFB];
+            auto split = [&](int bj) {                           // right-hand side, border and the three bf16 parts of block bj
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = xr[j][bj >> 2][bj & 3];
+                    racc[bj] += x * pj[j];
+                    if constexpr (BORDER) bacc[bj] += x * bwj[j];
+                    const float sx = x * swj[j];
+                    const __bf16 h = (__bf16)sx;
+                    const float r1 = sx - (float)h;
+                    const __bf16 m = (__bf16)r1;
+                    hi[bj][j] = h; mid[bj][j] = m; lo3[bj][j] = (__bf16)(r1 - (float)m);
+                }
+            };
+            // Block column by block column, the split of column bj + 1 in front of the MFMAs of column bj, which it does not
+            // depend on.  (__builtin_amdgcn_sched_barrier between the columns made hipcc interleave the two, but the result
+            // was wrong and varied from run to run -- a hazard the compiler no longer covers across such a barrier -- and
+            // no faster; sched_group_barrier patterns were ignored.  Left to itself it hoists most of the split in front of
+            // a burst of MFMAs.)
+            split(0);
+#pragma unroll
+            for (int bj = 0; bj < NFB; ++bj) {
+                if (bj + 1 < NFB) split(bj + 1);
+#pragma unroll
+                for (int bi = 0; bi <= bj; ++bi) {
+                    const int tt = tile_w<NFB>(bi, bj);
+                    f32x4 c = acc[tt];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo3[bi], hi[bj], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[bi], mid[bj], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], lo3[bj], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[bi], hi[bj], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], mid[bj], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], hi[bj], c, 0, 0, 0);
+                    acc[tt] = c;
+                }
+            }
+        };
         for (int G0 = 0; G0 < ngroups; G0 += DL_R) {
-            [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
-                (step(std::integral_constant<int, Ss>{}, G0 + Ss), ...);
-            }(std::make_integer_sequence<int, DL_R>{});
+            if constexpr (X6) {
+                chunk(std::integral_constant<int, 0>{}, G0);
+                chunk(std::integral_constant<int, 2>{}, G0 + 2);
+            } else {
+                [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
+                    (step(std::integral_constant<int, Ss>{}, G0 + Ss), ...);
+                }(std::make_integer_sequence<int, DL_R>{});
+            }
         }
-        if (itn < count) prime(lon, dn, mbn, true);      // the next row's first 48 entries fly during the elimination
+        if (itn < count) prime(lon, dn, mbn, !(X6 && (dbg & 32768)));      // the next row's first entries fly during the elimination
 
         // ---- C, D: block elimination and backward pass (wmf_dw_elim.h), w_p in registers
         bool ok = true;
@@ -265,11 +387,11 @@ int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const
     const int64_t cap = 256 * 4 * 3;                             // resident waves (one per SIMD), three rounds queued
     const dim3 grid((unsigned)(count < cap ? count : cap));
     const int dbg = wmf_debug_flags;
-    if (f == 129)
-        hipLaunchKernelGGL((solve_directl_kernel<true>), grid, dim3(64), DL_LDS, st, rows, count, V, indptr, indices, vals, f, ld, g,
-                           fb_rows, fb_count, dbg);
-    else
-        hipLaunchKernelGGL((solve_directl_kernel<false>), grid, dim3(64), DL_LDS, st, rows, count, V, indptr, indices, vals, f, ld, g,
-                           fb_rows, fb_count, dbg);
+    const bool x6 = !(dbg & 8192);                              // debug flag 8192: f32 MFMA accumulation
+#define DL_LAUNCH(B, X) hipLaunchKernelGGL((solve_directl_kernel<B, X>), grid, dim3(64), DL_LDS, st, rows, count, V, indptr, indices, \
+                                           vals, f, ld, g, fb_rows, fb_count, dbg)
+    if (f == 129) { if (x6) DL_LAUNCH(true, true); else DL_LAUNCH(true, false); }
+    else          { if (x6) DL_LAUNCH(false, true); else DL_LAUNCH(false, false); }
+#undef DL_LAUNCH
     return 0;
 }
