@@ -26,16 +26,17 @@
 
 #include <utility>
 
-#define DL_NFB 8
 #ifndef DL_GJ_LDS
 #define DL_GJ_LDS 0                 // multiplier column of the tile inverse: 1 = ds_bpermute, 0 = two VALU lane swaps
 #endif
 #define DL_R 4                      // ring slots = groups per 64-entry block (the group loop is unrolled by it)
-#define DL_SLOT 8192                // bytes: 16 rows x 512
-#define DL_META (DL_R * DL_SLOT)    // idx[4][64], w[4][64], border[4][64] behind the ring: metadata of block b in buffer b & 3
-#define DL_W 1024                   // (block b + 1 is requested while groups of b - 1 are still being consumed: three live blocks)
-#define DL_BD 2048
-#define DL_LDS (DL_META + 3 * 1024)
+#define DL_W 1024                   // metadata behind the ring: idx[4][64], w[4][64], border[4][64], block b in buffer b & 3
+#define DL_BD 2048                  // (block b + 1 is requested while groups of b - 1 are still being consumed: three live blocks)
+// per width (NFB = 4: f = 64 / 65, NFB = 8: f = 128 / 129): bytes of the feature part of a row, of a 16-entry slot, of the ring
+#define DL_RB(NFB) (64 * (NFB))
+#define DL_SLOTB(NFB) (16 * DL_RB(NFB))
+#define DL_METAB(NFB) (DL_R * DL_SLOTB(NFB))
+#define DL_LDSB(NFB) (DL_METAB(NFB) + 3 * 1024)
 
 typedef const __attribute__((address_space(1))) void* dl_gptr;
 typedef __attribute__((address_space(3))) void* dl_lptr;
@@ -72,26 +73,30 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // whitening, not here).  A chunk = two ring slots = 32 entries; lane (r, q) takes entries 8 q .. 8 q + 7 of the chunk
 // (the K index of its MFMA operands).  A negative weight has no square root: the NaN it produces reaches the pivot test
 // and the row is bounced to the pivoted kernel, like every system that is not positive definite.
-template <bool BORDER, bool X6>
-__global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __restrict__ rows, int64_t count, const float* __restrict__ V,
+template <int NFB, bool BORDER, bool X6>
+__global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(const int32_t* __restrict__ rows, int64_t count, const float* __restrict__ V,
                                                               const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                               const float* __restrict__ vals, int f, int ld, float* __restrict__ g,
                                                               int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int dbg) {
-    constexpr int NFB = DL_NFB, NT = NFB * (NFB + 1) / 2;
+    constexpr int NT = NFB * (NFB + 1) / 2;
+    constexpr int RB = DL_RB(NFB), DL_SLOT = DL_SLOTB(NFB), DL_META = DL_METAB(NFB);   // row bytes, slot bytes, metadata offset
+    constexpr int J = NFB / 4;                  // 16-byte pieces per lane and entry (pieces r, r + 16, ..)
+    constexpr int PP = 4 * NFB;                 // pieces per row; one DMA instruction moves 64 / PP rows
+    constexpr int EPI = 64 / PP, NI = 16 / EPI; // entries per DMA instruction, DMA instructions per 16-entry group
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
-    const int r = lane & 15, q = lane >> 4, h = lane >> 5;
+    const int r = lane & 15, q = lane >> 4, h = lane / PP;
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);   // LDS byte address of the region
     int baddr[4];
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) baddr[kq] = (r + 16 * kq) * 4;
     // LDS byte addresses of this lane's reads (inline asm below)
-    const unsigned ring_rd = lds0 + q * 512 + r * 16;                              // + slot * 8192 + t * 2048 + j * 256
+    const unsigned ring_rd = lds0 + q * RB + r * 16;                                // + slot * DL_SLOT + t * 4 RB + piece * 256
     const unsigned meta_rd = lds0 + DL_META + q * 4;                               // + (block & 3) * 256 + (group in block * 16 + 2 t) * 4
     const unsigned idx8_rd = lds0 + DL_META + h * 4;                              // + (block & 3) * 256 + group in block * 64
-    const unsigned ring6_rd = lds0 + q * 4096 + r * 16;                     // X6: entries 8 q + j of a chunk: + slot * 8192 + j * 512 + piece * 256
+    const unsigned ring6_rd = lds0 + q * 8 * RB + r * 16;                   // X6: entries 8 q + j of a chunk: + slot * DL_SLOT + j * RB + piece * 256
     const unsigned meta6_rd = lds0 + DL_META + q * 32;                     // X6: their eight weights / border values
-    const int piece = (lane & 31) * 4;                                      // first float of this lane's piece
+    const int piece = (lane % PP) * 4;                                      // first float of this lane's piece
 
     // The ring starts as zeros.  A chunk of the X6 path reads 32 ring positions even where the row has fewer entries left;
     // those positions are cancelled by weight 0, which only works on finite data: after this, whatever is stale in the ring
@@ -122,19 +127,24 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
             float iv = dl_read32<0>(lds0 + DL_META + par + lane * 4);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(iv)::"memory");     // the value passes through the wait: no use can move above it
             const int idx = __builtin_bit_cast(int, iv);
-            __builtin_amdgcn_global_load_lds((dl_gptr)(V + (int64_t)idx * ld + 128), (dl_lptr)(smem + DL_META + DL_BD + par), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((dl_gptr)(V + (int64_t)idx * ld + 16 * NFB), (dl_lptr)(smem + DL_META + DL_BD + par), 4, 0, 0);
         }
     };
     // the 16 rows of group gi (S = gi % 4 = its ring slot and its position in the block) -> 8 DMA instructions
     auto issue_rows = [&](auto slot, int gi, int base) {
         constexpr int S = decltype(slot)::value;
         const unsigned par = ((base + (gi >> 2)) & 3) * 256;
-        f32x2 i0 = dl_read2<S * 16, S * 16 + 2>(idx8_rd + par), i1 = dl_read2<S * 16 + 4, S * 16 + 6>(idx8_rd + par);
-        f32x2 i2 = dl_read2<S * 16 + 8, S * 16 + 10>(idx8_rd + par), i3 = dl_read2<S * 16 + 12, S * 16 + 14>(idx8_rd + par);
+        // this lane's rows: entries EPI i + h of the group, i = 0 .. NI - 1
+        f32x2 i0 = dl_read2<S * 16, S * 16 + EPI>(idx8_rd + par), i1 = dl_read2<S * 16 + 2 * EPI, S * 16 + 3 * EPI>(idx8_rd + par);
+        f32x2 i2 = f32x2{0.f, 0.f}, i3 = f32x2{0.f, 0.f};       // (not copies of i0: it is still in flight)
+        if constexpr (NI == 8) {
+            i2 = dl_read2<S * 16 + 4 * EPI, S * 16 + 5 * EPI>(idx8_rd + par);
+            i3 = dl_read2<S * 16 + 6 * EPI, S * 16 + 7 * EPI>(idx8_rd + par);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3)::"memory");
-        const float ids[8] = {i0[0], i0[1], i1[0], i1[1], i2[0], i2[1], i3[0], i3[1]};      // entries 2 i + h, i = 0 .. 7
+        const float ids[8] = {i0[0], i0[1], i1[0], i1[1], i2[0], i2[1], i3[0], i3[1]};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int idx = __builtin_bit_cast(int, ids[i]);
             __builtin_amdgcn_global_load_lds((dl_gptr)(V + (int64_t)idx * ld + piece), (dl_lptr)(smem + S * DL_SLOT + i * 1024), 16, 0, 0);
         }
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
                 constexpr int SN = (S + 3) & 3;
                 if constexpr (SN == 0) {
                     // metadata of block gn / 4 was requested 32 operations ago (its own group requests and three more)
-                    dl_wait_vm<32>();
+                    dl_wait_vm<4 * NI>();
                     issue_border(gn >> 2, mb);
                     if (64 * ((gn >> 2) + 1) < d) issue_meta((gn >> 2) + 1, lo, d, mb);
                 }
@@ -199,9 +209,9 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
             if (last && itn < count) issue_meta(0, lon, dn, mbn);
             // group G has landed when only the requests made after it are outstanding
             const int younger = min(3, ngroups - 1 - G);
-            if (younger >= 3) dl_wait_vm<24>();
-            else if (younger == 2) dl_wait_vm<16>();
-            else if (younger == 1) dl_wait_vm<8>();
+            if (younger >= 3) dl_wait_vm<3 * NI>();
+            else if (younger == 2) dl_wait_vm<2 * NI>();
+            else if (younger == 1) dl_wait_vm<NI>();
             else if (itn < count) dl_wait_vm<2>();       // only the next row's two metadata requests are younger
             else dl_wait_vm<0>();
             if (dbg & 2) return;
@@ -213,8 +223,9 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
             float wv[2], bf[2] = {0.f, 0.f};
             auto request = [&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                xa[t & 1] = dl_read128<S * DL_SLOT + t * 2048>(ring_rd);
-                xb[t & 1] = dl_read128<S * DL_SLOT + t * 2048 + 256>(ring_rd);
+                xa[t & 1] = dl_read128<S * DL_SLOT + t * 4 * RB>(ring_rd);
+                if constexpr (J == 2) xb[t & 1] = dl_read128<S * DL_SLOT + t * 4 * RB + 256>(ring_rd);
+                else xb[t & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 wv[t & 1] = dl_read32<DL_W + (S * 16 + 4 * t) * 4>(meta_rd + par);
                 if constexpr (BORDER) bf[t & 1] = dl_read32<DL_BD + (S * 16 + 4 * t) * 4>(meta_rd + par);
             };
@@ -227,8 +238,10 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
                 if constexpr (t < 3) { if (t + 1 < nk) request(std::integral_constant<int, t + 1>{}); }
                 const bool real = 16 * G + 4 * t + q < d;
                 const float w = real ? wraw : 0.f, p = real ? wraw + 1.f : 0.f;
-                const float x[NFB] = {ya[0], ya[1], ya[2], ya[3], yb[0], yb[1], yb[2], yb[3]};
-                float fw[NFB];
+                const float x8[8] = {ya[0], ya[1], ya[2], ya[3], yb[0], yb[1], yb[2], yb[3]};
+                float x[NFB], fw[NFB];
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) x[fb] = x8[fb];
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) { fw[fb] = x[fb] * w; racc[fb] += x[fb] * p; }
                 if constexpr (BORDER) {
@@ -259,15 +272,21 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
             // groups G, G + 1 have landed when only what was requested after them is outstanding: groups G + 2, G + 3
             const int younger = max(0, min(2, ngroups - G - 2));
             if (dbg & 16384) dl_wait_vm<0>();
-            else if (younger == 2) dl_wait_vm<16>();
-            else if (younger == 1) dl_wait_vm<8>();
+            else if (younger == 2) dl_wait_vm<2 * NI>();
+            else if (younger == 1) dl_wait_vm<NI>();
             else if (itn < count) dl_wait_vm<2>();
             else dl_wait_vm<0>();
             // all LDS operands of the chunk into registers: 8 entries x 2 pieces, their weights and border values
             const unsigned par = ((mb + (G >> 2)) & 3) * 256;
             f32x4 xr[8][2], wq[2], bq[2];
+            auto read_entry = [&](auto jc) {
+                constexpr int jj = decltype(jc)::value;
+                xr[jj][0] = dl_read128<S * DL_SLOT + jj * RB>(ring6_rd);
+                if constexpr (J == 2) xr[jj][1] = dl_read128<S * DL_SLOT + jj * RB + 256>(ring6_rd);
+                else xr[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            };
             [&]<int... Js>(std::integer_sequence<int, Js...>) {
-                ((xr[Js][0] = dl_read128<S * DL_SLOT + Js * 512>(ring6_rd), xr[Js][1] = dl_read128<S * DL_SLOT + Js * 512 + 256>(ring6_rd)), ...);
+                (read_entry(std::integral_constant<int, Js>{}), ...);
             }(std::make_integer_sequence<int, 8>{});
             wq[0] = dl_read128<DL_W + S * 64>(meta6_rd + par);
             wq[1] = dl_read128<DL_W + S * 64 + 16>(meta6_rd + par);
@@ -370,7 +389,7 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
                 g[(int64_t)u * ld + c] = gb[p];
             }
             if constexpr (BORDER) {
-                const int c = 128 + r;                            // the border column and the padding behind it
+                const int c = 16 * NFB + r;                       // the border column and the padding behind it
                 if (c < ld) g[(int64_t)u * ld + c] = (r == 0) ? tb : 0.f;
             }
         }
@@ -378,20 +397,25 @@ __global__ __launch_bounds__(64, 1) void solve_directl_kernel(const int32_t* __r
     }
 }
 
-int wmf_directl_supported(int f, int ld) { return (f == 128 && ld == 128) || (f == 129 && ld == 132); }
+int wmf_directl_supported(int f, int ld) {
+    return (f == 128 && ld == 128) || (f == 129 && ld == 132) || (f == 64 && ld == 64) || (f == 65 && ld == 68);
+}
 
 int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const int64_t* indptr, const int32_t* indices,
                        const float* vals, int f, int ld, float* g, int32_t* fb_rows, int32_t* fb_count, hipStream_t st) {
     if (count <= 0) return 0;
     if (!wmf_directl_supported(f, ld)) return -1;
-    const int64_t cap = 256 * 4 * 3;                             // resident waves (one per SIMD), three rounds queued
+    const int nfb = f / 16;                                      // 4 or 8 (the bias column is a border)
+    const int64_t cap = 256 * 4 * (nfb <= 4 ? 2 : 1) * 3;        // resident waves, three rounds queued
     const dim3 grid((unsigned)(count < cap ? count : cap));
     const int dbg = wmf_debug_flags;
     const bool x6 = !(dbg & 8192);                              // debug flag 8192: f32 MFMA accumulation
-#define DL_LAUNCH(B, X) hipLaunchKernelGGL((solve_directl_kernel<B, X>), grid, dim3(64), DL_LDS, st, rows, count, V, indptr, indices, \
-                                           vals, f, ld, g, fb_rows, fb_count, dbg)
-    if (f == 129) { if (x6) DL_LAUNCH(true, true); else DL_LAUNCH(true, false); }
-    else          { if (x6) DL_LAUNCH(false, true); else DL_LAUNCH(false, false); }
+#define DL_LAUNCH(N, B, X) hipLaunchKernelGGL((solve_directl_kernel<N, B, X>), grid, dim3(64), DL_LDSB(N), st, rows, count, V, indptr, \
+                                              indices, vals, f, ld, g, fb_rows, fb_count, dbg)
+#define DL_PICK(N) do { if (f % 16) { if (x6) DL_LAUNCH(N, true, true); else DL_LAUNCH(N, true, false); } \
+                        else        { if (x6) DL_LAUNCH(N, false, true); else DL_LAUNCH(N, false, false); } } while (0)
+    if (nfb == 4) DL_PICK(4); else DL_PICK(8);
+#undef DL_PICK
 #undef DL_LAUNCH
     return 0;
 }

@@ -283,7 +283,8 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
     const int32_t* rows = pl->rows[WMF_BIN_MFMA];
     const int64_t normal = pl->count[WMF_BIN_MFMA] - pl->heavy_count;
     // k = 128 with or without biases: the LDS-DMA ring kernel (wmf_directl.hip); debug flag 4096 keeps the register ring
-    if (normal > 0 && biasv == nullptr && wmf_directl_supported(f, ld) && !(dbg & 4096)) {
+    // (f = 64 / 65 can run there too, debug flag 65536, but gains nothing: cfg2 item side 1.34 ms against 1.30 here)
+    if (normal > 0 && biasv == nullptr && wmf_directl_supported(f, ld) && !(dbg & 4096) && (f >= 128 || (dbg & 65536))) {
         (void)wmf_launch_directl(rows, normal, V, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, st);
     } else if (normal > 0)
         hipLaunchKernelGGL((solve_directw_kernel<NFB, 0, BORDER>), dim3((unsigned)(normal < cap ? normal : cap)), dim3(64), 0, st,

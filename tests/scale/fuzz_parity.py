@@ -1,7 +1,7 @@
 """Randomised parity sweep (not a pytest): many (k, bias, shape, degree law) combinations, one half step each through the
 host entry point against the C oracle (oracle/wmf_oracle.c, float64).  Widths are drawn to hit every kernel family and
 the boundaries between them (f = 16, 17, 32, 33, 48, 49, 64, 65, 113, 128, 129, 144, 145, 160, 161, 256, 257, 258, 260).
-Usage: python tests/scale/fuzz_parity.py [cases] [seed]"""
+Usage: python tests/scale/fuzz_parity.py [cases] [seed] [f1,f2,...]"""
 import sys, time
 import numpy as np, scipy.sparse as sp
 sys.path.insert(0, '.')
@@ -10,12 +10,13 @@ from oracle import c_oracle
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+ONLY = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else None      # optional: draw widths from this list only
 FS = [1, 2, 3, 5, 15, 16, 17, 31, 32, 33, 47, 48, 49, 50, 63, 64, 65, 80, 81, 96, 97, 112, 113, 127, 128, 129, 130, 143, 144, 145, 146,
       159, 160, 161, 176, 177, 200, 208, 209, 240, 241, 255, 256, 257, 258, 260]
 worst = 0.0
 t0 = time.perf_counter()
 for case in range(cases):
-    f = int(rng.choice(FS))
+    f = int(rng.choice(ONLY if ONLY else FS))
     bias = bool(rng.integers(2)) and f >= 2
     k = f - int(bias)
     m = int(rng.integers(max(2 * f, 40), 4 * f + 200))              # fixed side: enough rows for a decent Gramian
