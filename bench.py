@@ -126,7 +126,7 @@ def measured_traffic(config, slot, f, ld):
     nfb_heavy = f // 16 if (f > 16 and f % 16 == 1 and (f // 16) % 4 != 3) else nfb     # border variant of the heavy-row kernel
     heavy = f"solve_directw_kernel<{nfb_heavy}, 0"
     if (f, ld) in ((128, 128), (129, 132)):                          # k = 128: the LDS-DMA ring kernel (wmf_directl.hip)
-        heavy = "solve_directl_kernel<" + ("true" if f == 129 else "false")
+        heavy = "solve_directl_kernel<8, " + ("true" if f == 129 else "false")
     key = {0: f"gram_kernel<{nfb}, 1>", 3: f"transform_kernel<{nfb}, true", 4: f"solve_low_kernel<{nch}, 1,",
            5: f"solve_low_kernel<{nch}, 2", 11: heavy}.get(slot)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config}_traffic.json")))
