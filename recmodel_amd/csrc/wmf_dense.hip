@@ -82,6 +82,91 @@ __device__ __forceinline__ void gram_body(const float* __restrict__ Y, int64_t m
     }
 }
 
+// The same Gramian with split-bf16 products (wide factors, where the f32 MFMAs of gram_body are what bounds the kernel:
+// 1.6 ms for 11 M rows at f = 129): a chunk of 32 rows per trip, lane (r, q) loads Y~[32 c + 8 q + j][16 fb + r], j = 0..7
+// -- the K index of a 16x16x32 MFMA -- splits every value into three bf16 parts (exact) and issues six bf16 MFMAs per tile
+// (lo.hi, mid.mid, hi.lo, mid.hi, hi.mid, hi.hi; the dropped products are below 2^-24 of the term): the accuracy of the
+// f32 path at 6 x 16 instead of 8 x 32 MFMA cycles per tile and 32 rows.
+typedef __bf16 gram_bf16x8 __attribute__((ext_vector_type(8)));
+template <int NFB>
+__device__ __forceinline__ void gram_body6(const float* __restrict__ Y, int64_t m, int f, int ld, int bias,
+                                           float* __restrict__ partial, int64_t step_lo, int64_t step_hi) {
+    constexpr int NT = NFB * (NFB + 1) / 2;
+    const int lane = threadIdx.x;
+    const int r = lane & 15, q = lane >> 4;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int last_col = min(16 * (NFB - 1) + r, ld - 1);
+    const float col_mask_last = (16 * (NFB - 1) + r < f) ? 1.f : 0.f;
+    const int64_t row_lo = 4 * step_lo, row_hi = min(4 * step_hi, m);          // this wave's rows [row_lo, row_hi)
+    float cur[8][NFB], nxt[8][NFB];
+    auto load_chunk = [&](int64_t c0, float (&fr)[8][NFB]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t row = min(c0 + 8 * q + j, m - 1);                     // clamped: masked at use
+            const float* yrow = Y + row * (int64_t)ld;
+#pragma unroll
+            for (int fb = 0; fb < NFB - 1; ++fb) fr[j][fb] = yrow[16 * fb + r];
+            fr[j][NFB - 1] = yrow[last_col];
+        }
+    };
+    if (row_lo < row_hi) load_chunk(row_lo, cur);
+    for (int64_t c0 = row_lo; c0 < row_hi; c0 += 32) {
+        if (c0 + 32 < row_hi) load_chunk(c0 + 32, nxt);
+        gram_bf16x8 hi[NFB], mid[NFB], lo[NFB];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float rmask = (c0 + 8 * q + j < row_hi) ? 1.f : 0.f;
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) {
+                float x = cur[j][fb] * rmask;
+                if (fb == NFB - 1) x *= col_mask_last;
+                if (fb == 0 && bias && r == 0) x = rmask;                       // column 0 reads as 1 (wmf_model.py:331)
+                const __bf16 h = (__bf16)x;
+                const float r1 = x - (float)h;
+                const __bf16 md = (__bf16)r1;
+                hi[fb][j] = h; mid[fb][j] = md; lo[fb][j] = (__bf16)(r1 - (float)md);
+            }
+        }
+        int t = 0;
+#pragma unroll
+        for (int bi = 0; bi < NFB; ++bi) {
+#pragma unroll
+            for (int bj = bi; bj < NFB; ++bj, ++t) {
+                f32x4 c = acc[t];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo[bi], hi[bj], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[bi], mid[bj], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], lo[bj], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[bi], hi[bj], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], mid[bj], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], hi[bj], c, 0, 0, 0);
+                acc[t] = c;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) cur[j][fb] = nxt[j][fb];
+    }
+    float* out = partial + (int64_t)blockIdx.x * NT * 256;                     // partial layout: [wave][tile][reg][lane]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) out[(t * 4 + reg) * 64 + lane] = acc[t][reg];
+}
+
+template <int NFB>
+__global__ __launch_bounds__(64) void gram6_kernel(const float* __restrict__ Y, int64_t m, int f, int ld, int bias,
+                                                   float* __restrict__ partial, int64_t steps_per_wave) {
+    const int64_t nsteps = (m + 3) / 4;
+    int64_t lo = (int64_t)blockIdx.x * steps_per_wave;
+    int64_t hi = lo + steps_per_wave;
+    if (hi > nsteps) hi = nsteps;
+    if (lo > hi) lo = hi;
+    gram_body6<NFB>(Y, m, f, ld, bias, partial, lo, hi);
+}
+
 template <int NFB, int NSPLIT>
 __global__ __launch_bounds__(64) void gram_kernel(const float* __restrict__ Y, int64_t m, int f, int ld, int bias,
                                                   float* __restrict__ partial, int64_t steps_per_wave) {
@@ -139,6 +224,12 @@ static int launch_gram_nfb(const float* Y, int64_t m, int f, int ld, int bias, f
                            hipStream_t st) {
     const int64_t nsteps = (m + 3) / 4;
     const int64_t spw = (nsteps + nwaves - 1) / nwaves;
+    if constexpr (NFB >= 7 && NFB <= 9) {                     // wide and still one accumulator set per wave: split-bf16 products
+        if (!(wmf_debug_flags & 131072)) {                    // (debug flag 131072: the f32 MFMA kernel)
+            hipLaunchKernelGGL((gram6_kernel<NFB>), dim3(nwaves), dim3(64), 0, st, Y, m, f, ld, bias, partial, spw);
+            return 0;
+        }
+    }
     if constexpr (NFB <= 9) {
         hipLaunchKernelGGL((gram_kernel<NFB, 1>), dim3(nwaves), dim3(64), 0, st, Y, m, f, ld, bias, partial, spw);
     } else {
