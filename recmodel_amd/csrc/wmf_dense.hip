@@ -816,6 +816,143 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
     }
 }
 
+// The same product with split-bf16 MFMAs for wide factors (f = 97 .. 144), where the f32 MFMAs bound the kernel above (180 of
+// them per 16-row block at f = 129 against a 1.3 ms HBM floor for 10 M rows).  W is split ONCE into three bf16 planes, stored
+// transposed in LDS (plane p, output column n, k contiguous: the eight k of a lane's 16x16x32 B operand are one ds_read_b128;
+// row stride 176 bf16 = 88 dwords: the 16 lanes that share an LDS cycle of a ds_read_b128 -- {0-3, 12-15, 20-27} .. -- then hit
+// 64 distinct banks; at 84 dwords three pairs of them collided and the kernel ran at half speed); the rows of `in` are split on
+// the fly (a lane's A operand of K chunk c is the two 16-byte pieces 8 c + 2 q, 8 c + 2 q + 1 of its row).  Six MFMAs per
+// (32-wide K chunk, output block) whose W tile is not all zero: 25 of 45 pairs for a triangular W at f = 129.
+template <int NFB>
+__global__ __launch_bounds__(512) void transform6_kernel(const float* __restrict__ in, int64_t m, int f, int ld,
+                                                         const float* __restrict__ W, int set_col0_one,
+                                                         float* __restrict__ out, float* __restrict__ col0_out,
+                                                         int64_t nblocks16) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NP = 16 * NFB;                 // output columns, padded
+    constexpr int NKC = (NP + 31) / 32;          // K chunks of 32
+    constexpr int KS = 176;                      // bf16 elements per LDS row (>= 32 NKC = 160): 88 dwords, see above
+    static_assert(32 * NKC <= KS, "K does not fit the LDS row");
+    __bf16* Wt = reinterpret_cast<__bf16*>(smem_raw);             // [3][NP][KS]
+    __shared__ int nz[NKC * NFB];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NKC * NFB; e += 512) nz[e] = 0;
+    __syncthreads();
+    for (int e = tid; e < NP * KS; e += 512) {
+        const int n = e / KS, k = e % KS;
+        const float v = (k < f && n < f) ? W[k * ld + n] : 0.f;
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 md = (__bf16)r1;
+        Wt[e] = h;
+        Wt[NP * KS + e] = md;
+        Wt[2 * NP * KS + e] = (__bf16)(r1 - (float)md);
+        if (v != 0.f) nz[(k >> 5) * NFB + (n >> 4)] = 1;          // benign race: every writer stores 1
+    }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int nch = ld >> 2;
+    unsigned cmask[NKC];                         // per K chunk: output blocks with a non-zero tile of W
+#pragma unroll
+    for (int c = 0; c < NKC; ++c) {
+        unsigned mk = 0;
+#pragma unroll
+        for (int nb = 0; nb < NFB; ++nb) mk |= nz[c * NFB + nb] ? (1u << nb) : 0u;
+        cmask[c] = __builtin_amdgcn_readfirstlane(mk);
+    }
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    const bf16x8_t* Wl = reinterpret_cast<const bf16x8_t*>(Wt);    // 16-byte units: element (p, n, k8) at ((p NP + n) KS + 8 k8) / 8
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    auto request = [&](int64_t blk, float4 (&x)[2 * NKC]) {
+        const int64_t row = blk * 16 + r;
+        const float4* irow = reinterpret_cast<const float4*>(in + (row < m ? row : 0) * (int64_t)ld);   // loads are unconditional
+#pragma unroll
+        for (int c = 0; c < NKC; ++c) {
+            x[2 * c] = irow[min(8 * c + 2 * q, nch - 1)];
+            x[2 * c + 1] = irow[min(8 * c + 2 * q + 1, nch - 1)];
+        }
+    };
+    auto block = [&](int64_t blk, float4 (&xc)[2 * NKC]) {
+        const int64_t row = blk * 16 + r;
+        const bool rok = row < m;
+        f32x4 acc[NFB];
+#pragma unroll
+        for (int nb = 0; nb < NFB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NKC; ++c) {
+            const int k0 = 32 * c + 8 * q;                       // first k of this lane's eight
+            float xe[8] = {xc[2 * c].x, xc[2 * c].y, xc[2 * c].z, xc[2 * c].w, xc[2 * c + 1].x, xc[2 * c + 1].y, xc[2 * c + 1].z, xc[2 * c + 1].w};
+            if (32 * c + 32 > f) {                               // only the last chunk(s) can run past the f features (loads were clamped)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (!(k0 + e < f)) xe[e] = 0.f;
+            }
+            if (c == 0 && set_col0_one && q == 0) {
+                if (rok && col0_out) col0_out[row] = xe[0];
+                xe[0] = 1.f;
+            }
+            bf16x8_t ah, am, al;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 h = (__bf16)xe[e];
+                const float r1 = xe[e] - (float)h;
+                const __bf16 md = (__bf16)r1;
+                ah[e] = h; am[e] = md; al[e] = (__bf16)(r1 - (float)md);
+            }
+            unsigned mv = cmask[c];
+            asm volatile("" : "+v"(mv));                         // test the bits here (hoisted, the branch conditions spill)
+            const unsigned mk = __builtin_amdgcn_readfirstlane(mv);
+#pragma unroll
+            for (int nb = 0; nb < NFB; ++nb) {
+                if (!(mk & (1u << nb))) continue;                // wave-uniform: an all-zero 32 x 16 tile of W
+                const int at = ((16 * nb + r) * KS + 32 * c + 8 * q) / 8;
+                const bf16x8_t bh = Wl[at], bm = Wl[NP * KS / 8 + at], bl = Wl[2 * NP * KS / 8 + at];
+                f32x4 cc = acc[nb];
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, cc, 0, 0, 0);
+                acc[nb] = cc;
+            }
+        }
+        // acc[nb][reg] = out[blk*16 + 4q + reg][16 nb + r]
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t orow = blk * 16 + 4 * q + reg;
+            if (orow < m) {
+                float* o = out + orow * (int64_t)ld;
+#pragma unroll
+                for (int nb = 0; nb < NFB; ++nb) {
+                    const int col = 16 * nb + r;
+                    if (col < ld) o[col] = acc[nb][reg];
+                }
+            }
+        }
+    };
+    // one block of pieces at a time (two, as in transform_kernel, spill at 256 registers: the bf16 parts need room)
+    float4 xa[2 * NKC];
+    for (int64_t blk = (int64_t)blockIdx.x * 8 + wv; blk < nblocks16; blk += stride) {
+        request(blk, xa);
+        block(blk, xa);
+    }
+}
+
+template <int NFB>
+static void launch_transform6(const float* in, int64_t m, int f, int ld, const float* W, int set_col0_one, float* out,
+                              float* col0_out, int64_t grid, int64_t nblk, hipStream_t st) {
+    constexpr size_t lds = (size_t)3 * 16 * NFB * 176 * 2;
+    static_assert(lds <= 158 * 1024, "W planes do not fit LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)transform6_kernel<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((transform6_kernel<NFB>), dim3((unsigned)grid), dim3(512), lds, st, in, m, f, ld, W, set_col0_one, out,
+                       col0_out, nblk);
+}
+
 template <int NFB, int NB0, int NBW>
 static void launch_transform_slice(const float* in, int64_t m, int f, int ld, const float* W, int set_col0_one, float* out,
                                    float* col0_out, int64_t grid, int64_t nblk, hipStream_t st) {
@@ -840,6 +977,12 @@ static void launch_transform_nfb(const float* in, int64_t m, int f, int ld, cons
     int64_t grid = (nblk + 7) / 8;
     if (grid > 1024) grid = 1024;
     if (grid < 1) grid = 1;
+    if constexpr (NFB >= 7 && NFB <= 9) {                     // wide factors: split-bf16 products (debug flag 262144: f32 MFMAs)
+        if (!(wmf_debug_flags & 262144)) {
+            launch_transform6<NFB>(in, m, f, ld, W, set_col0_one, out, col0_out, grid, nblk, st);
+            return;
+        }
+    }
     if constexpr (lds <= 150 * 1024) {
         launch_transform_slice<NFB, 0, NFB>(in, m, f, ld, W, set_col0_one, out, col0_out, grid, nblk, st);
     } else if (in != out) {
