@@ -85,8 +85,14 @@ __device__ __forceinline__ void gj_sweep(float (&m)[NSETS][NSETS * 4], float (&p
 #endif
 // d <= 16 rows are latency bound: six waves per SIMD (<= 80 registers, no spills up to NCH = 9) measured 15 % faster
 // than the five the compiler settles on at k = 128; the d <= 32 kernel needs its 100 registers.
-template <int NCH, int NSETS, bool BLK>
-__global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : 1) void solve_low_kernel(const int32_t* __restrict__ rows, int64_t count,
+// X6 (NSETS == 2, ld a multiple of 32): the three S tiles by split-bf16 products.  A lane then takes the pieces
+// 8 c + 2 q, 8 c + 2 q + 1 of its rows (the eight k of chunk c's 16x16x32 MFMA operand) instead of 4 t + q; every gathered
+// value is split into three bf16 parts (exact) and each tile gets six bf16 MFMAs per 32 features instead of eight f32
+// ones.  A bf16 MFMA holds the SIMD's shared pipe for 8 of its 16 cycles, an f32 one for all 32: with five waves per SIMD the
+// other waves' VALU work runs beside it.
+typedef __bf16 low_bf16x8 __attribute__((ext_vector_type(8)));
+template <int NCH, int NSETS, bool BLK, bool X6 = false>
+__global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 4) ? 5 : 1)) void solve_low_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                         const float* __restrict__ V, const float* __restrict__ biasv,
                                                         const int64_t* __restrict__ indptr,
                                                         const int32_t* __restrict__ indices,
@@ -130,10 +136,15 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : 1) void solve_l
         w[s] = wj;
         p[s] = wj + am;
         const float4* vrow = Vq + (int64_t)idx * nch;
+        if constexpr (X6) {                          // pieces 8 c + 2 q + h, all inside the row (ld is a multiple of 32)
 #pragma unroll
-        for (int t = 0; t < NCH - 1; ++t) x[s][t] = vrow[4 * t];
-        const float4 v = (vrow - q)[last_c];
-        x[s][NCH - 1] = make_float4(v.x * last_m, v.y * last_m, v.z * last_m, v.w * last_m);
+            for (int t = 0; t < NCH; ++t) x[s][t] = (vrow - q)[8 * (t >> 1) + 2 * q + (t & 1)];
+        } else {
+#pragma unroll
+            for (int t = 0; t < NCH - 1; ++t) x[s][t] = vrow[4 * t];
+            const float4 v = (vrow - q)[last_c];
+            x[s][NCH - 1] = make_float4(v.x * last_m, v.y * last_m, v.z * last_m, v.w * last_m);
+        }
     }
     if (__any(neg)) {                               // wave-uniform: bounce the row to the LU kernel
         if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;
@@ -162,8 +173,40 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : 1) void solve_l
         for (int s = 0; s < NSETS; ++s)
 #pragma unroll
             for (int c = 0; c < NSETS; ++c) acc[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (X6) {
+            static_assert(NSETS == 2 && NCH % 2 == 0, "X6: two sets, whole 32-feature chunks");
 #pragma unroll
-        for (int t = 0; t < NCH; ++t) {
+            for (int cc = 0; cc < NCH / 2; ++cc) {
+                low_bf16x8 hi[2], mid[2], lo[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const float xe[8] = {x[s][2 * cc].x, x[s][2 * cc].y, x[s][2 * cc].z, x[s][2 * cc].w,
+                                         x[s][2 * cc + 1].x, x[s][2 * cc + 1].y, x[s][2 * cc + 1].z, x[s][2 * cc + 1].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const __bf16 h = (__bf16)xe[e];
+                        const float r1 = xe[e] - (float)h;
+                        const __bf16 md = (__bf16)r1;
+                        hi[s][e] = h; mid[s][e] = md; lo[s][e] = (__bf16)(r1 - (float)md);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int c = s; c < 2; ++c) {                 // tile (s, c): A from set c, B from set s, as the f32 path
+                        f32x4 a = acc[s][c];
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo[c], hi[s], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[c], mid[s], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[c], lo[s], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[c], hi[s], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[c], mid[s], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[c], hi[s], a, 0, 0, 0);
+                        acc[s][c] = a;
+                    }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < (X6 ? 0 : NCH); ++t) {
             if constexpr (NSETS == 1) {
                 acc[0][0] = WMF_MFMA16(x[0][t].x, x[0][t].x, acc[0][0]);
                 acc1 = WMF_MFMA16(x[0][t].y, x[0][t].y, acc1);
@@ -295,7 +338,7 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : 1) void solve_l
 #if !(WMF_LOW_ABLATE & 4)
         wmf_row16_sum4(y.x, y.y, y.z, y.w);
 #endif
-        const int c = 4 * t + q;
+        const int c = X6 ? 8 * (t >> 1) + 2 * q + (t & 1) : 4 * t + q;      // the piece this lane holds in slot t
         if (r == 0 && c < nch) grow[c] = y;
     }
 }
@@ -605,7 +648,12 @@ static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, c
             hipLaunchKernelGGL((solve_low_kernel<NCH, 2, false>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
                                pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
                                pl->fallback_count);
-        else
+        else if (NCH % 2 == 0 && ld % 32 == 0 && !(wmf_debug_flags & 524288)) {    // split-bf16 S tiles (flag 524288: f32)
+            if constexpr (NCH % 2 == 0)
+                hipLaunchKernelGGL((solve_low_kernel<NCH, 2, true, true>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
+                                   pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
+                                   pl->fallback_count);
+        } else
             hipLaunchKernelGGL((solve_low_kernel<NCH, 2, true>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
                                pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
                                pl->fallback_count);
