@@ -282,6 +282,10 @@ def main():
         "unit": "row-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "precision_note": "float32 storage, float32 accumulation everywhere; Gramian fp64 across waves; where a kernel is "
+                          "MFMA-bound its products are three-way bf16 splits of the float32 operands (six bf16 MFMAs per tile, "
+                          "every product exact, result within 1.4x of the f32-MFMA error: DESIGN.md section 5); parity tolerance "
+                          "unchanged (tests/test_gpu_parity.py)",
         "config": {"workload": f"{args.config}: WMF k={k}{'+bias' if bias else ''}, {n_users}x{n_items} CSR, "
                                f"{nnz} nnz, alpha-log confidence, gamma={gamma}, zipf_a={args.zipf}",
                    "n_users": n_users, "n_items": n_items, "nnz": nnz, "k": k, "bias": bias,
