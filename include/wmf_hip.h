@@ -192,7 +192,15 @@ int wmf_eliminate_rows(float* partial, int64_t n, int32_t slots_per_row, int f, 
 int         wmf_profile_enable(int on);
 int         wmf_profile_read(double* ms, int64_t* launches);
 const char* wmf_profile_slot_name(int slot);
-/* Kernel-ablation switches for timing experiments (results are WRONG when non-zero); default 0. */
+/* Kernel-selection and ablation switches for timing experiments (tools/kernel_lab.py); default 0.
+ *   ablation, results are WRONG:  1 no elimination, 2 no accumulation MFMAs, 4 (rows with <= 32 entries) no row sums,
+ *                                 8 no tile inverse in the elimination
+ *   earlier designs of the same step, results stay correct:
+ *       16 workgroup-per-row heavy kernel, 128 one wave per row with an LDS image (f <= 64), 64 plain 32 x 32 Gauss-Jordan
+ *       for rows with 17..32 entries, 256 no border column, 1024 run-time-indexed eight-wave kernel for f > 144,
+ *       2048 no two-rows-per-wave kernel, 4096 register-ring heavy kernel at k = 128 (instead of the LDS-DMA ring),
+ *       8192 f32 MFMA accumulation in the LDS-DMA kernel, 65536 LDS-DMA kernel also for f = 64 / 65,
+ *       131072 f32 Gramian and 262144 f32 row transform for f = 97 .. 144, 524288 f32 S tiles for rows with 17..32 entries. */
 int         wmf_debug_set_flags(int flags);
 
 #ifdef __cplusplus

@@ -268,11 +268,10 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             constexpr int S = decltype(slot)::value;
             if (G >= ngroups) return;
             const bool lastc = G + 2 >= ngroups;                 // the row's last chunk
-            if (lastc && itn < count && !(dbg & 32768)) issue_meta(0, lon, dn, mbn);
+            if (lastc && itn < count) issue_meta(0, lon, dn, mbn);
             // groups G, G + 1 have landed when only what was requested after them is outstanding: groups G + 2, G + 3
             const int younger = max(0, min(2, ngroups - G - 2));
-            if (dbg & 16384) dl_wait_vm<0>();
-            else if (younger == 2) dl_wait_vm<2 * NI>();
+            if (younger == 2) dl_wait_vm<2 * NI>();
             else if (younger == 1) dl_wait_vm<NI>();
             else if (itn < count) dl_wait_vm<2>();
             else dl_wait_vm<0>();
@@ -373,7 +372,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
                 }(std::make_integer_sequence<int, DL_R>{});
             }
         }
-        if (itn < count) prime(lon, dn, mbn, !(X6 && (dbg & 32768)));      // the next row's first entries fly during the elimination
+        if (itn < count) prime(lon, dn, mbn, true);      // the next row's first entries fly during the elimination
 
         // ---- C, D: block elimination and backward pass (wmf_dw_elim.h), w_p in registers
         bool ok = true;
