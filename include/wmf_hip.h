@@ -193,8 +193,7 @@ int         wmf_profile_enable(int on);
 int         wmf_profile_read(double* ms, int64_t* launches);
 const char* wmf_profile_slot_name(int slot);
 /* Kernel-selection and ablation switches for timing experiments (tools/kernel_lab.py); default 0.
- *   ablation, results are WRONG:  1 no elimination, 2 no accumulation MFMAs, 4 (rows with <= 32 entries) no row sums,
- *                                 8 no tile inverse in the elimination
+ *   ablation, results are WRONG:  1 no elimination, 2 no accumulation MFMAs, 8 no tile inverse in the elimination
  *   earlier designs of the same step, results stay correct:
  *       16 workgroup-per-row heavy kernel, 128 one wave per row with an LDS image (f <= 64), 64 plain 32 x 32 Gauss-Jordan
  *       for rows with 17..32 entries, 256 no border column, 1024 run-time-indexed eight-wave kernel for f > 144,
