@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
                                                         const float* __restrict__ V, const float* __restrict__ biasv,
                                                         const int64_t* __restrict__ indptr,
                                                         const int32_t* __restrict__ indices,
-                                                        const float* __restrict__ vals, int ld, float* __restrict__ g,
+                                                        const float* __restrict__ vals, int ld, int last1, float* __restrict__ g,
                                                         int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count) {
     const int lane = threadIdx.x & 63;
     // wave-uniform values are forced into SGPRs: hipcc cannot see that threadIdx.x >> 6 is uniform, and
@@ -207,17 +207,22 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
         }
 #pragma unroll
         for (int t = 0; t < (X6 ? 0 : NCH); ++t) {
+            // last1: the row's last piece holds ONE feature (f = 4 m + 1, e.g. k = 128 with the bias column) and three padding
+            // zeros: three of its four k-steps would multiply zeros
+            const bool tail_only = (t == NCH - 1) && last1;
             if constexpr (NSETS == 1) {
                 acc[0][0] = WMF_MFMA16(x[0][t].x, x[0][t].x, acc[0][0]);
-                acc1 = WMF_MFMA16(x[0][t].y, x[0][t].y, acc1);
-                acc[0][0] = WMF_MFMA16(x[0][t].z, x[0][t].z, acc[0][0]);
-                acc1 = WMF_MFMA16(x[0][t].w, x[0][t].w, acc1);
+                if (!tail_only) {
+                    acc1 = WMF_MFMA16(x[0][t].y, x[0][t].y, acc1);
+                    acc[0][0] = WMF_MFMA16(x[0][t].z, x[0][t].z, acc[0][0]);
+                    acc1 = WMF_MFMA16(x[0][t].w, x[0][t].w, acc1);
+                }
             } else {
                 // S_BA = S_AB^T is not accumulated: it is one tile transpose (4 MFMAs against the identity) below
 #define WMF_S4(E)                                                                   \
     _Pragma("unroll") for (int s = 0; s < NSETS; ++s)                               \
         _Pragma("unroll") for (int c = s; c < NSETS; ++c) acc[s][c] = WMF_MFMA16(x[c][t].E, x[s][t].E, acc[s][c]);
-                WMF_S4(x) WMF_S4(y) WMF_S4(z) WMF_S4(w)
+                WMF_S4(x) WMF_S4(y) WMF_S4(z) WMF_S4(w)       // (no tail skip here: the branch cost this kernel more than the 9 MFMAs)
 #undef WMF_S4
             }
         }
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(256, NCH <= 9 ? 6 : 1) void solve_pair_kernel(const
                                                                           const float* __restrict__ V, const float* __restrict__ biasv,
                                                                           const int64_t* __restrict__ indptr,
                                                                           const int32_t* __restrict__ indices,
-                                                                          const float* __restrict__ vals, int ld, float* __restrict__ g,
+                                                                          const float* __restrict__ vals, int ld, int last1, float* __restrict__ g,
                                                                           int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -406,9 +411,11 @@ __global__ __launch_bounds__(256, NCH <= 9 ? 6 : 1) void solve_pair_kernel(const
 #pragma unroll
     for (int t = 0; t < NCH; ++t) {
         a0 = WMF_MFMA16(x[t].x, x[t].x, a0);
-        a1 = WMF_MFMA16(x[t].y, x[t].y, a1);
-        a0 = WMF_MFMA16(x[t].z, x[t].z, a0);
-        a1 = WMF_MFMA16(x[t].w, x[t].w, a1);
+        if (!((t == NCH - 1) && last1)) {              // (a last piece of one feature and three padding zeros: solve_low_kernel)
+            a1 = WMF_MFMA16(x[t].y, x[t].y, a1);
+            a0 = WMF_MFMA16(x[t].z, x[t].z, a0);
+            a1 = WMF_MFMA16(x[t].w, x[t].w, a1);
+        }
     }
     // M = I + D S restricted to the two diagonal 8 x 8 blocks: this lane's columns are 4q + reg, i.e. block q >> 1
     const float keep = (second == (q >= 2)) ? 1.f : 0.f;
@@ -626,36 +633,36 @@ void wmf_launch_bias_adjust(const float* vals, const int32_t* indices, const flo
 // ------------------------------------------------------------------------------------- launchers
 template <int NCH>
 static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
-                       const int32_t* indices, const float* vals, int ld, float* g, hipStream_t st) {
+                       const int32_t* indices, const float* vals, int ld, int last1, float* g, hipStream_t st) {
     const int64_t c0 = pl->count[WMF_BIN_LOW16], c1 = pl->count[WMF_BIN_LOW32];
     // rows with at most 8 entries come first in the bin and go two per wave (solve_pair_kernel)
     const int64_t c8 = (wmf_debug_flags & 2048) ? 0 : pl->count8;
     if (c8 > 0) {
         WmfProfScope ps(WMF_SLOT_SOLVE_LOW16, st);
         hipLaunchKernelGGL((solve_pair_kernel<NCH>), dim3((unsigned)(((c8 + 1) / 2 + 3) / 4)), dim3(256), 0, st,
-                           pl->rows[WMF_BIN_LOW16], c8, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
+                           pl->rows[WMF_BIN_LOW16], c8, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
                            pl->fallback_count);
     }
     if (c0 - c8 > 0) {
         WmfProfScope ps(WMF_SLOT_SOLVE_LOW16, st);
         hipLaunchKernelGGL((solve_low_kernel<NCH, 1, false>), dim3((unsigned)((c0 - c8 + 3) / 4)), dim3(256), 0, st,
-                           pl->rows[WMF_BIN_LOW16] + c8, c0 - c8, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
+                           pl->rows[WMF_BIN_LOW16] + c8, c0 - c8, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
                            pl->fallback_count);
     }
     if (c1 > 0) {
         WmfProfScope ps(WMF_SLOT_SOLVE_LOW32, st);
         if (wmf_debug_flags & 64)       // plain 32 x 32 Gauss-Jordan, kept for A/B timing
             hipLaunchKernelGGL((solve_low_kernel<NCH, 2, false>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
-                               pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
+                               pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
                                pl->fallback_count);
         else if (NCH % 2 == 0 && ld % 32 == 0 && !(wmf_debug_flags & 524288)) {    // split-bf16 S tiles (flag 524288: f32)
             if constexpr (NCH % 2 == 0)
                 hipLaunchKernelGGL((solve_low_kernel<NCH, 2, true, true>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
-                                   pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
+                                   pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
                                    pl->fallback_count);
         } else
             hipLaunchKernelGGL((solve_low_kernel<NCH, 2, true>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
-                               pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, g, pl->fallback_rows,
+                               pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
                                pl->fallback_count);
     }
 }
@@ -703,7 +710,7 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
         biasv = nullptr;
     }
     switch ((ld + 15) / 16) {
-#define C(N) case N: launch_low<N>(pl, V, biasv, indptr, indices, vals, ld, g, st); break;
+#define C(N) case N: launch_low<N>(pl, V, biasv, indptr, indices, vals, ld, (f % 4 == 1 && ld == f + 3 && (ld / 4) % 4 == 1) ? 1 : 0, g, st); break;   /* the lanes' last slot holds that one piece only */
         C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)
 #undef C
         default: return -1;
