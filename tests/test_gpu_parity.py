@@ -271,7 +271,7 @@ def test_short_rows_share_a_wave(WMF, k, bias, neg):
         assert np.all(got[deg == 0] == 0)
 
 
-@pytest.mark.parametrize("k", [16, 256])
+@pytest.mark.parametrize("k", [16, 64, 128, 256])       # 128: the split-bf16 heavy-row kernel (a negative weight has no square root there)
 def test_negative_weights_take_the_pivoted_path(WMF, k):
     """bias model with large fixed-side biases: w - bias < 0 for many entries, so A_u is not SPD
      and the rows must go through the LU kernel (LDS version for f <= 144, the
