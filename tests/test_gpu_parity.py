@@ -271,6 +271,46 @@ def test_short_rows_share_a_wave(WMF, k, bias, neg):
         assert np.all(got[deg == 0] == 0)
 
 
+@pytest.mark.parametrize("bias", [False, True])
+def test_many_heavy_rows_per_wave_at_k128(WMF, bias):
+    """More heavy rows than resident waves (8000 against 3072), 33 .. 400 entries each, k = 128: every wave of the LDS-DMA
+    kernel walks several rows -- next row's metadata requested during the last group, its first rows during the elimination,
+    the metadata buffers rotating across rows -- and must give what the register-ring f32 kernel (debug flag 4096) gives, row
+    by row, and satisfy the rows' own normal equations in float64."""
+    from recmodel_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11 + bias)
+    n, m_items, k = 8000, 3000, 128
+    deg = rng.integers(33, 401, n)
+    deg[:50] = rng.integers(33, 66, 50)
+    rows = np.repeat(np.arange(n), deg)
+    cols = np.concatenate([np.sort(rng.choice(m_items, d, replace=False)) for d in deg])
+    vals = (10 * np.log(1 + rng.integers(1, 6, rows.size))).astype(np.float32)
+    C = sp.csr_matrix((vals, (rows, cols)), shape=(n, m_items))
+    model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=bias)
+    Y = model.items.copy()
+    if bias:
+        Y[:, 0] *= 0.5                                                 # weights stay positive: the SPD kernels are used
+    step = model.recompute_factors_bias if bias else model.recompute_factors
+    try:
+        lib.wmf_debug_set_flags(4096)
+        ref = step(Y, C, 0.1).astype(np.float64)
+    finally:
+        lib.wmf_debug_set_flags(0)
+    got = step(Y, C, 0.1).astype(np.float64)
+    rel = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert rel.max() <= 5e-6, (rel.max(), int(rel.argmax()), int(deg[rel.argmax()]))
+    Yt, bvec = Y.astype(np.float64).copy(), np.zeros(m_items)
+    if bias:
+        bvec, Yt[:, 0] = Yt[:, 0].copy(), 1.0
+    G = Yt.T @ Yt + 0.1 * np.eye(Y.shape[1])
+    for u in rng.choice(n, 40, replace=False):
+        lo, hi = C.indptr[u], C.indptr[u + 1]
+        U, w = Yt[C.indices[lo:hi]], C.data[lo:hi].astype(np.float64) - bvec[C.indices[lo:hi]]
+        A, b = G + U.T @ (U * w[:, None]), (w + 1) @ U
+        assert np.linalg.norm(A @ got[u] - b) <= 2e-5 * np.linalg.norm(b)
+
+
 @pytest.mark.parametrize("k", [16, 64, 128, 256])       # 128: the split-bf16 heavy-row kernel (a negative weight has no square root there)
 def test_negative_weights_take_the_pivoted_path(WMF, k):
     """bias model with large fixed-side biases: w - bias < 0 for many entries, so A_u is not SPD
