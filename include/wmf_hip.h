@@ -16,7 +16,8 @@
  *   - "host" entry points take host pointers and are self-contained (own hipMalloc/copies).
  *   - "device" entry points take device pointers and a hipStream_t passed as void*; they only
  *     enqueue work (no allocation, no synchronisation) so a caller can keep factors resident in
- *     HBM across half steps and put collectives between them.
+ *     HBM across half steps and put collectives between them.  Whatever device memory a solve needs
+ *     beyond the caller's buffers is allocated by wmf_plan_create and freed by wmf_plan_destroy.
  *   - factor matrices are row-major fp32 with a leading dimension `ld` (floats), ld % 4 == 0,
  *     ld >= f; the padding columns [f, ld) must be zero on input and are written as zero.
  *     f = k (no bias) or k+1 (bias: column 0 is the bias, wmf_model.py:328-331).
@@ -73,7 +74,9 @@ int wmf_gram(const float* Y, int64_t m, int f, int ld, int bias,
  * fp32 transforms used by the row solve, both [f, ld] row-major, zero padded:
  *   W_white[a][b]   = (L^-T)[a][b]     V = Y~ . W_white      (whitened fixed factors)
  *   W_unwhite[a][b] = (L^-1)[a][b]     X = g  . W_unwhite    (back to factor space)
- * info (device int32): 0 = ok, j > 0 = leading minor j not positive definite.
+ * info (device int32, caller zeroes): left alone on success, set to j > 0 when leading minor j is not positive
+ * definite -- sticky, so one check after several half steps still sees a failure of the first (the outputs of a
+ * failed factorisation are zero matrices).
  * Replaces the `+ lambda_reg * np.eye(...)` of wmf_model.py:215/332 and the shared part of the
  * per-row np.linalg.solve of :239/:350. */
 int wmf_factorize(const double* G_sum, int f, int ld, double lambda,
@@ -86,12 +89,17 @@ int wmf_factorize(const double* G_sum, int f, int ld, double lambda,
 int wmf_row_transform(const float* in, int64_t m, int f, int ld, const float* W,
                       int set_col0_one, float* out, float* col0_out, void* stream);
 
-/* Degree-binned schedule for the rows of one CSR matrix (built once per matrix, host indptr). */
-int  wmf_plan_create(const int64_t* indptr_host, int64_t n, int f, wmf_plan** out);
+/* Degree-binned schedule for the rows of one CSR matrix (built once per matrix, host indptr).  Allocates (and
+ * synchronously fills) the plan's device memory, including everything wmf_solve_rows will need: the row lists, the
+ * segment table of rows with more than 4096 entries, with bias != 0 the bias-adjusted weights (one float per stored
+ * entry, wmf_model.py:343), for f > 144 the workspace of the pivoted fallback.  A plan created with bias = 0 cannot
+ * be solved with a bias vector. */
+int  wmf_plan_create(const int64_t* indptr_host, int64_t n, int f, int bias, wmf_plan** out);
 void wmf_plan_destroy(wmf_plan* p);
-/* Rows and stored entries the plan routes to each kernel family: out8[b] = rows, out8[4+b] =
- * stored entries, for b = 0: <=16 entries, 1: 17..32, 2: MFMA Gramian path, 3: general LU path. */
-int  wmf_plan_stats(const wmf_plan* p, int64_t* out8);
+/* Rows and stored entries the plan routes to each kernel family: out10[b] = rows, out10[4+b] =
+ * stored entries, for b = 0: <=16 entries, 1: 17..32, 2: MFMA Gramian path, 3: general LU path;
+ * out10[8], out10[9] = rows and entries of bin 0 with at most 8 entries (two rows share a wave). */
+int  wmf_plan_stats(const wmf_plan* p, int64_t* out10);
 
 /* The per-row normal-equation solve in whitened coordinates, for every row of the CSR:
  *   g_u = (I + V_u^T D_u V_u)^-1 V_u^T (w_u + 1),   V_u = V[idx_u], D_u = diag(w_u)
@@ -184,23 +192,27 @@ int wmf_eliminate_rows(float* partial, int64_t n, int32_t slots_per_row, int f, 
                        int32_t* scratch, void* stream);
 
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------------- */
-/* When enabled, every kernel launch of the device-level entry points is bracketed by HIP events
- * on its own stream.  wmf_profile_read() waits for them and ADDS, per kernel slot, the elapsed
- * milliseconds and the launch count into ms[WMF_PROF_SLOTS] / launches[WMF_PROF_SLOTS], then
- * forgets the events.  Slot names: wmf_profile_slot_name(). */
-#define WMF_PROF_SLOTS 12
-int         wmf_profile_enable(int on);
-int         wmf_profile_read(double* ms, int64_t* launches);
-const char* wmf_profile_slot_name(int slot);
-/* Kernel-selection and ablation switches for timing experiments (tools/kernel_lab.py); default 0.
- *   ablation, results are WRONG:  1 no elimination, 2 no accumulation MFMAs, 8 no tile inverse in the elimination
- *   earlier designs of the same step, results stay correct:
- *       16 workgroup-per-row heavy kernel, 128 one wave per row with an LDS image (f <= 64), 64 plain 32 x 32 Gauss-Jordan
- *       for rows with 17..32 entries, 256 no border column, 1024 run-time-indexed eight-wave kernel for f > 144,
- *       2048 no two-rows-per-wave kernel, 4096 register-ring heavy kernel at k = 128 (instead of the LDS-DMA ring),
- *       8192 f32 MFMA accumulation in the LDS-DMA kernel, 65536 LDS-DMA kernel also for f = 64 / 65,
- *       131072 f32 Gramian and 262144 f32 row transform for f = 97 .. 144, 524288 f32 S tiles for rows with 17..32 entries. */
-int         wmf_debug_set_flags(int flags);
+/* While enabled, every kernel launch of the device-level entry points is bracketed by two HIP events on its own
+ * stream.  wmf_profile_collect() waits for the events recorded so far, folds them into a table with one entry per
+ * (kernel symbol, tag) and returns the number of entries; wmf_profile_entry(i, ...) reads entry i: the kernel's name as
+ * rocprofv3 prints it, up to and including its template arguments ("solve_low_kernel<9, 1, false, false>"), the tag,
+ * total / min / max milliseconds and the launch count.  The tag is whatever wmf_profile_set_tag() last set (bench.py:
+ * 0 = users half step, 1 = items half step), so the launches of one kernel on the two sides are kept apart.
+ * wmf_profile_reset() empties the table.  All five are thread-safe. */
+int wmf_profile_enable(int on);
+int wmf_profile_set_tag(int tag);
+int wmf_profile_collect(void);
+int wmf_profile_entry(int i, char* name, int name_cap, int* tag, double* ms, int64_t* launches, double* min_ms, double* max_ms);
+int wmf_profile_reset(void);
+/* Kernel-SELECTION switches for timing experiments (tools/kernel_lab.py); default 0, process-wide, not synchronised
+ * with running solves.  Every selection computes the same results (the parity suite runs under each of them):
+ *       64 plain 32 x 32 Gauss-Jordan for rows with 17..32 entries, 256 no border column, 1024 run-time-indexed eight-wave
+ *       kernel for f > 144, 2048 no two-rows-per-wave kernel, 4096 register-ring heavy kernel at k = 128 (instead of the
+ *       LDS-DMA ring), 8192 f32 MFMA accumulation in the LDS-DMA kernel, 65536 LDS-DMA kernel also for f = 64 / 65,
+ *       131072 f32 Gramian and 262144 f32 row transform for f = 97 .. 144, 524288 f32 S tiles for rows with 17..32 entries.
+ * The ablation switches 1 / 2 / 8 (no elimination / no accumulation MFMAs / no tile inverse: results WRONG) exist only
+ * in a -DWMF_LAB build; the shipped library returns WMF_EINVAL for them. */
+int wmf_debug_set_flags(int flags);
 
 #ifdef __cplusplus
 }

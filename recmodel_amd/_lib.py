@@ -17,7 +17,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WMF_HIP_LIB", os.path.join(_HERE, "libwmf_hip.so"))   # override: kernel tuning experiments
 
 WMF_OK, WMF_EINVAL, WMF_EHIP, WMF_ENOMEM, WMF_ENUMERIC = 0, -1, -2, -3, -4
-WMF_PROF_SLOTS = 12
 
 c_int, c_i64, c_dbl, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
 
@@ -31,7 +30,7 @@ SIGNATURES = {
     "wmf_gram": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "wmf_factorize": (c_int, [c_vp, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wmf_row_transform": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
-    "wmf_plan_create": (c_int, [c_vp, c_i64, c_int, ctypes.POINTER(c_vp)]),
+    "wmf_plan_create": (c_int, [c_vp, c_i64, c_int, c_int, ctypes.POINTER(c_vp)]),
     "wmf_plan_destroy": (None, [c_vp]),
     "wmf_plan_stats": (c_int, [c_vp, c_vp]),
     "wmf_solve_rows": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
@@ -49,9 +48,11 @@ SIGNATURES = {
     "wmf_spmm_rows": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "wmf_confidence_transform": (c_int, [c_vp, c_i64, c_dbl, c_dbl, c_int, c_vp]),
     "wmf_profile_enable": (c_int, [c_int]),
+    "wmf_profile_set_tag": (c_int, [c_int]),
+    "wmf_profile_collect": (c_int, []),
+    "wmf_profile_entry": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "wmf_profile_reset": (c_int, []),
     "wmf_debug_set_flags": (c_int, [c_int]),
-    "wmf_profile_read": (c_int, [c_vp, c_vp]),
-    "wmf_profile_slot_name": (ctypes.c_char_p, [c_int]),
 }
 
 
@@ -81,6 +82,21 @@ def load():
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def profile_table(lib=None):
+    """[(kernel symbol, tag, total ms, launches, min ms, max ms)] of the launches recorded since the last reset
+    (wmf_profile_collect / wmf_profile_entry)."""
+    lib = lib or load()
+    out = []
+    name = ctypes.create_string_buffer(200)
+    tag, n = c_int(), c_i64()
+    ms, lo, hi = c_dbl(), c_dbl(), c_dbl()
+    for i in range(lib.wmf_profile_collect()):
+        check(lib.wmf_profile_entry(i, name, 200, ctypes.byref(tag), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(lo),
+                                    ctypes.byref(hi)))
+        out.append((name.value.decode(), tag.value, ms.value, n.value, lo.value, hi.value))
+    return out
 
 
 def check(rc):

@@ -4,9 +4,13 @@
 #include "../../include/wmf_hip.h"
 #include "wmf_internal.h"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -45,48 +49,97 @@ static int check_shape(int f, int ld) {
 }
 
 // ---- per-kernel event timing ------------------------------------------------------------------
-struct ProfRec { int slot; hipEvent_t a, b; };
-static bool g_prof_on = false;
+// Launch sites bracket every kernel with two events on its own stream (WMF_LAUNCH / WmfProfScope) while profiling is on.
+// wmf_profile_collect() waits for the events and folds them into a table keyed by (kernel symbol, tag); the tag is
+// whatever wmf_profile_set_tag() last set (bench.py: 0 = users half step, 1 = items half step), so the two launches of
+// one kernel per iteration are reported separately.  One mutex guards all of it: the entry points may be called from
+// several host threads (one per stream).
+struct ProfRec { const char* name; int tag; hipEvent_t a, b; };
+struct ProfAgg { const char* name; int tag; double ms, min_ms, max_ms; int64_t launches; };
+static std::mutex g_prof_mu;
+static std::atomic<bool> g_prof_on{false};
+static int g_prof_tag = 0;
 static std::vector<ProfRec> g_prof;
-static ProfRec g_prof_open;
-static bool g_prof_is_open = false;
+static std::vector<ProfAgg> g_prof_table;
+static thread_local ProfRec g_prof_open;
+static thread_local bool g_prof_is_open = false;
 
-void wmf_prof_begin(int slot, hipStream_t st) {
-    if (!g_prof_on) return;
-    ProfRec r; r.slot = slot;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+const char* wmf_kname(const char* fmt, ...) {
+    char buf[192];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    static std::mutex mu;
+    static std::set<std::string> names;
+    std::lock_guard<std::mutex> lk(mu);
+    return names.insert(buf).first->c_str();       // node-based container: the string never moves
+}
+
+void wmf_prof_begin(const char* name, hipStream_t st) {
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    ProfRec r; r.name = name;
+    if (hipEventCreate(&r.a) != hipSuccess) return;
+    if (hipEventCreate(&r.b) != hipSuccess) { (void)hipEventDestroy(r.a); return; }
+    { std::lock_guard<std::mutex> lk(g_prof_mu); r.tag = g_prof_tag; }
     (void)hipEventRecord(r.a, st);
     g_prof_open = r; g_prof_is_open = true;
 }
 void wmf_prof_end(hipStream_t st) {
-    if (!g_prof_on || !g_prof_is_open) return;
+    if (!g_prof_is_open) return;
     (void)hipEventRecord(g_prof_open.b, st);
-    g_prof.push_back(g_prof_open);
     g_prof_is_open = false;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(g_prof_open);
 }
 
 extern "C" {
 
-int wmf_debug_set_flags(int flags) { wmf_debug_flags = flags; return WMF_OK; }
-int wmf_profile_enable(int on) { g_prof_on = on != 0; return WMF_OK; }
-int wmf_profile_read(double* ms, int64_t* launches) {
+int wmf_debug_set_flags(int flags) {
+#ifndef WMF_LAB
+    // Ablation switches that make results WRONG (1, 2, 8) exist only in a -DWMF_LAB build (tools/build_variant.sh)
+    if (flags & (1 | 2 | 8)) { wmf_set_error("wmf_debug_set_flags: ablation flags 1/2/8 need a -DWMF_LAB build"); return WMF_EINVAL; }
+#endif
+    wmf_debug_flags = flags;
+    return WMF_OK;
+}
+int wmf_profile_enable(int on) { g_prof_on.store(on != 0); return WMF_OK; }
+int wmf_profile_set_tag(int tag) { std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_tag = tag; return WMF_OK; }
+int wmf_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_table.clear();
+    return WMF_OK;
+}
+int wmf_profile_collect(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) {
         float t = 0.f;
-        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess &&
-            r.slot >= 0 && r.slot < WMF_PROF_SLOTS) {
-            if (ms) ms[r.slot] += t;
-            if (launches) launches[r.slot] += 1;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            ProfAgg* hit = nullptr;
+            for (auto& e : g_prof_table) if (e.name == r.name && e.tag == r.tag) { hit = &e; break; }
+            if (!hit) { g_prof_table.push_back(ProfAgg{r.name, r.tag, 0.0, 1e300, 0.0, 0}); hit = &g_prof_table.back(); }
+            hit->ms += t; hit->launches += 1;
+            if (t < hit->min_ms) hit->min_ms = t;
+            if (t > hit->max_ms) hit->max_ms = t;
         }
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
-    return WMF_OK;
+    return (int)g_prof_table.size();
 }
-const char* wmf_profile_slot_name(int slot) {
-    static const char* names[WMF_PROF_SLOTS] = {"gram_kernel", "gram_reduce_kernel", "factorize_kernel", "transform_kernel",
-        "solve_low_kernel<.,1>", "solve_low_kernel<.,2>", "solve_general_kernel(heavy)", "solve_general_kernel(fallback)",
-        "eval_kernel", "predict_kernel", "bias_adjust/spmm", "solve_direct_kernel"};
-    return (slot >= 0 && slot < WMF_PROF_SLOTS) ? names[slot] : "?";
+int wmf_profile_entry(int i, char* name, int name_cap, int* tag, double* ms, int64_t* launches, double* min_ms, double* max_ms) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (i < 0 || i >= (int)g_prof_table.size()) { wmf_set_error("wmf_profile_entry: index %d outside the table", i); return WMF_EINVAL; }
+    const ProfAgg& e = g_prof_table[(size_t)i];
+    if (name && name_cap > 0) { strncpy(name, e.name, (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+    if (tag) *tag = e.tag;
+    if (ms) *ms = e.ms;
+    if (launches) *launches = e.launches;
+    if (min_ms) *min_ms = e.min_ms;
+    if (max_ms) *max_ms = e.max_ms;
+    return WMF_OK;
 }
 
 const char* wmf_last_error(void) { return g_err; }
@@ -147,7 +200,7 @@ static int bin_of(int64_t d, int f) {
     return wmf_direct_supported(f) ? WMF_BIN_MFMA : WMF_BIN_GENERAL;
 }
 
-int wmf_plan_create(const int64_t* indptr, int64_t n, int f, wmf_plan** out) {
+int wmf_plan_create(const int64_t* indptr, int64_t n, int f, int bias, wmf_plan** out) {
     if (!indptr || !out || n < 0 || n > 0x7fffffffLL) { wmf_set_error("wmf_plan_create: bad arguments"); return WMF_EINVAL; }
     if (f < 1 || f > WMF_MAX_F) { wmf_set_error("wmf_plan_create: f=%d unsupported", f); return WMF_EINVAL; }
     wmf_plan* p = new wmf_plan();
@@ -169,7 +222,7 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, wmf_plan** out) {
     // first bin: rows with at most 8 entries first (two of them share a wave), the others behind them
     for (int64_t r = 0; r < n; ++r) {
         const int64_t d = indptr[r + 1] - indptr[r];
-        if (d <= 8) { order[(size_t)fill[WMF_BIN_LOW16]++] = (int32_t)r; p->count8++; }
+        if (d <= 8) { order[(size_t)fill[WMF_BIN_LOW16]++] = (int32_t)r; p->count8++; p->nnz8 += d; }
     }
     for (int64_t r = 0; r < n; ++r) {
         const int64_t d = indptr[r + 1] - indptr[r];
@@ -197,6 +250,12 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, wmf_plan** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&p->fallback_count, 256);
     if (e == hipSuccess && n > 0) e = hipMemcpy(p->rows_all, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(p->fallback_count, 0, 256);
+    // every buffer a solve may need is allocated here, so that wmf_solve_rows only enqueues work: the bias-adjusted
+    // weights of a biased model, the matrix slices of the pivoted fallback for f > 144
+    const int64_t nnz_all = p->nnz[0] + p->nnz[1] + p->nnz[2] + p->nnz[3];
+    p->bias = bias != 0;
+    if (e == hipSuccess && bias && nnz_all > 0) e = hipMalloc((void**)&p->w_eff, (size_t)nnz_all * sizeof(float));
+    if (e == hipSuccess && f > 144) e = hipMalloc((void**)&p->wide_ws, wmf_wide_lu_workspace_bytes(f));
     if (e == hipSuccess && p->heavy_count > 0) {
         const int64_t nfb = (f + 15) / 16, nt = nfb * (nfb + 1) / 2 + nfb;
         e = hipMalloc((void**)&p->seg_lo, seg_lo.size() * sizeof(int64_t));
@@ -231,9 +290,10 @@ void wmf_plan_destroy(wmf_plan* p) {
     delete p;
 }
 
-int wmf_plan_stats(const wmf_plan* p, int64_t* out8) {
+int wmf_plan_stats(const wmf_plan* p, int64_t* out8 /* int64[10] */) {
     if (!p || !out8) { wmf_set_error("wmf_plan_stats: null"); return WMF_EINVAL; }
     for (int b = 0; b < WMF_NBINS; ++b) { out8[b] = p->count[b]; out8[WMF_NBINS + b] = p->nnz[b]; }
+    out8[8] = p->count8; out8[9] = p->nnz8;
     return WMF_OK;
 }
 
@@ -243,10 +303,11 @@ int wmf_solve_rows(const wmf_plan* plan, const float* V, const float* bias_fixed
     int rc = check_shape(f, ld);
     if (rc) return rc;
     if (!plan || !V || !indptr || !g || !fail_count) { wmf_set_error("wmf_solve_rows: null pointer"); return WMF_EINVAL; }
+    if (bias_fixed && !plan->bias) { wmf_set_error("wmf_solve_rows: bias_fixed given, but the plan was created with bias = 0"); return WMF_EINVAL; }
     if (plan->n != n || plan->f != f) { wmf_set_error("wmf_solve_rows: plan was built for n=%lld f=%d", (long long)plan->n, plan->f); return WMF_EINVAL; }
     if (n == 0) return WMF_OK;
     const int lrc = wmf_launch_solve(plan, V, bias_fixed, indptr, indices, values, f, ld, g, fail_count, (hipStream_t)stream);
-    if (lrc == -2) { wmf_set_error("wmf_solve_rows: device allocation or memset failed"); return WMF_EHIP; }
+    if (lrc == -2) { wmf_set_error("wmf_solve_rows: hipMemsetAsync failed"); return WMF_EHIP; }
     if (lrc) { wmf_set_error("wmf_solve_rows: no kernel for f=%d, ld=%d", f, ld); return WMF_EINVAL; }
     return check_launch("wmf_solve_rows");
 }
@@ -301,7 +362,6 @@ int wmf_accumulate_rows(const float* V, const float* bias_fixed, const int64_t* 
         values = w_eff_workspace;
     }
     {
-        WmfProfScope ps(WMF_SLOT_SOLVE_DIRECT, st);
         if (wmf_launch_accumulate(V, indptr, degrees, indices, values, n, f, ld, partial, slot_stride, slot_offset, st)) { wmf_set_error("wmf_accumulate_rows: no kernel for f=%d", f); return WMF_EINVAL; }
     }
     return check_launch("wmf_accumulate_rows");
@@ -315,7 +375,6 @@ int wmf_eliminate_rows(float* partial, int64_t n, int32_t slots_per_row, int f, 
     if (wmf_directw_partial_floats(f) == 0) { wmf_set_error("wmf_eliminate_rows: f=%d not supported (f <= 144)", f); return WMF_EINVAL; }
     if (n == 0) return WMF_OK;
     {
-        WmfProfScope ps(WMF_SLOT_SOLVE_HEAVY, (hipStream_t)stream);
         if (wmf_launch_eliminate(partial, n, slots_per_row, f, ld, g, scratch, fail_count, (hipStream_t)stream)) { wmf_set_error("wmf_eliminate_rows: no kernel for f=%d", f); return WMF_EINVAL; }
     }
     return check_launch("wmf_eliminate_rows");
@@ -424,8 +483,9 @@ int wmf_recompute_factors_host(const float* Y_host, int64_t m, int f, int bias, 
         HIP_TRY(hipMemcpy(dVal.p, values, (size_t)nnz * 4, hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemset(dFail.p, 0, 16));
+    HIP_TRY(hipMemset(dInfo.p, 0, 16));
     wmf_plan* plan = nullptr;
-    int rc = wmf_plan_create(indptr, n, f, &plan);
+    int rc = wmf_plan_create(indptr, n, f, bias, &plan);
     if (rc) return rc;
     hipStream_t st = nullptr;
     rc = wmf_gram((const float*)dY.p, m, f, ld, bias, (double*)dG.p, dWs.p, st);

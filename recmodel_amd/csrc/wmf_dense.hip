@@ -226,14 +226,17 @@ static int launch_gram_nfb(const float* Y, int64_t m, int f, int ld, int bias, f
     const int64_t spw = (nsteps + nwaves - 1) / nwaves;
     if constexpr (NFB >= 7 && NFB <= 9) {                     // wide and still one accumulator set per wave: split-bf16 products
         if (!(wmf_debug_flags & 131072)) {                    // (debug flag 131072: the f32 MFMA kernel)
-            hipLaunchKernelGGL((gram6_kernel<NFB>), dim3(nwaves), dim3(64), 0, st, Y, m, f, ld, bias, partial, spw);
+            static const char* nm = wmf_kname("gram6_kernel<%d>", NFB);
+            WMF_LAUNCH(nm, (gram6_kernel<NFB>), dim3(nwaves), dim3(64), 0, st, Y, m, f, ld, bias, partial, spw);
             return 0;
         }
     }
     if constexpr (NFB <= 9) {
-        hipLaunchKernelGGL((gram_kernel<NFB, 1>), dim3(nwaves), dim3(64), 0, st, Y, m, f, ld, bias, partial, spw);
+        static const char* nm = wmf_kname("gram_kernel<%d, 1>", NFB);
+        WMF_LAUNCH(nm, (gram_kernel<NFB, 1>), dim3(nwaves), dim3(64), 0, st, Y, m, f, ld, bias, partial, spw);
     } else {
-        hipLaunchKernelGGL((gram_kernel<NFB, 4>), dim3(nwaves, 4), dim3(64), 0, st, Y, m, f, ld, bias, partial, spw);
+        static const char* nm = wmf_kname("gram_kernel<%d, 4>", NFB);
+        WMF_LAUNCH(nm, (gram_kernel<NFB, 4>), dim3(nwaves, 4), dim3(64), 0, st, Y, m, f, ld, bias, partial, spw);
     }
     return 0;
 }
@@ -259,18 +262,15 @@ int wmf_launch_gram(const float* Y, int64_t m, int f, int ld, int bias, double* 
     if (m <= 0) return hipMemsetAsync(G_sum, 0, (size_t)f * f * sizeof(double), st) == hipSuccess ? 0 : -1;
     const int nfb = (f + 15) / 16;
     const int nwaves = wmf_gram_nwaves(m, f);
-    WmfProfScope* ps = new WmfProfScope(WMF_SLOT_GRAM, st);
     switch (nfb) {
 #define C(N) case N: launch_gram_nfb<N>(Y, m, f, ld, bias, partial, nwaves, st); break;
         C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)
 #undef C
-        default: delete ps; return -1;
+        default: return -1;
     }
-    delete ps;
-    WmfProfScope ps2(WMF_SLOT_GRAM_REDUCE, st);
-    hipLaunchKernelGGL(gram_reduce1_kernel, dim3((f * f + 255) / 256, WMF_GRAM_SLICES), dim3(256), 0, st, partial, nwaves,
-                       f, nfb, slices);
-    hipLaunchKernelGGL(gram_reduce2_kernel, dim3((f * f + 255) / 256), dim3(256), 0, st, slices, f, G_sum);
+    WMF_LAUNCH("gram_reduce1_kernel", gram_reduce1_kernel, dim3((f * f + 255) / 256, WMF_GRAM_SLICES), dim3(256), 0, st, partial,
+               nwaves, f, nfb, slices);
+    WMF_LAUNCH("gram_reduce2_kernel", gram_reduce2_kernel, dim3((f * f + 255) / 256), dim3(256), 0, st, slices, f, G_sum);
     return 0;
 }
 
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void factorize_kernel(const double* __restrict
     }
     __syncthreads();
     const int fail = s_fail;
-    if (t == 0) *info = fail;
+    if (t == 0 && fail) *info = fail;          // sticky: only the caller resets it (a later success must not hide a failure)
     if (fail) {                       // poison nothing: write zero transforms so downstream stays finite
         for (int e = t; e < f * ld; e += 256) { Wwhite[e] = 0.f; Wunwhite[e] = 0.f; }
         return;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64, 1) void factorize64_kernel(const double* __rest
     }
     bool ok = true;
     chol64_sweep<FP>(a, ok, std::make_integer_sequence<int, FP>{});
-    if (lane == 0) *info = ok ? 0 : 1;
+    if (lane == 0 && !ok) *info = 1;           // sticky (see factorize_kernel)
     double x[FP];
     inv64_sweep<FP>(a, x, lane, std::make_integer_sequence<int, FP>{});
     // lane j holds column j of X = L^-1:  Wunwhite[i][j] = X[i][j],  Wwhite[j][i] = X[i][j]
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(64, 1) void factorize64m_kernel(const double* __res
             fz_store(tile(Xs, i, p), FZ_LD, c, r, q);
             sync();
         }
-    if (lane == 0) *info = ok ? 0 : 1;
+    if (lane == 0 && !ok) *info = 1;           // sticky (see factorize_kernel)
     // Wunwhite[i][j] = X[i][j],  Wwhite[j][i] = X[i][j]; padding columns [f, ld) zero
 #pragma unroll 8
     for (int i = 0; i < 64; ++i) {
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(512, 1) void factorize_blocked_kernel(const double*
         }
     __syncthreads();
     const bool ok = bad == 0;
-    if (tid == 0) *info = ok ? 0 : 1;
+    if (tid == 0 && !ok) *info = 1;            // sticky (see factorize_kernel)
     for (int e = tid; e < f * ld; e += 512) {
         const int i = e / ld, j = e % ld;
         float wu = 0.f, ww = 0.f;
@@ -648,12 +648,12 @@ __global__ __launch_bounds__(512, 1) void factorize_blocked_kernel(const double*
 int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, float* Wwhite, float* Wunwhite,
                          int32_t* info, double* gA, hipStream_t st) {
     if (f <= 64 && !(wmf_debug_flags & 512)) {       // blocked single-wave version (fp64 MFMA)
-        WmfProfScope ps(WMF_SLOT_FACTORIZE, st);
+        WmfProfScope ps("factorize64m_kernel", st);
         hipLaunchKernelGGL(factorize64m_kernel, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
         return 0;
     }
     if (f <= 64) {                                   // register-resident single-wave version (debug flag 512: A/B timing)
-        WmfProfScope ps(WMF_SLOT_FACTORIZE, st);
+        WmfProfScope ps("factorize64_kernel", st);
         if (f <= 16) hipLaunchKernelGGL(factorize64_kernel<16>, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
         else if (f <= 32) hipLaunchKernelGGL(factorize64_kernel<32>, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
         else if (f <= 48) hipLaunchKernelGGL(factorize64_kernel<48>, dim3(1), dim3(64), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info);
@@ -661,7 +661,7 @@ int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, floa
         return 0;
     }
     if (!(wmf_debug_flags & 512)) {                  // blocked workgroup version (fp64 MFMA); flag 512: the older kernel below
-        WmfProfScope ps(WMF_SLOT_FACTORIZE, st);
+        WmfProfScope ps("factorize_blocked_kernel", st);
         hipLaunchKernelGGL(factorize_blocked_kernel, dim3(1), dim3(512), 0, st, G_sum, f, ld, lambda, Wwhite, Wunwhite, info, gA);
         return 0;
     }
@@ -674,7 +674,7 @@ int wmf_launch_factorize(const double* G_sum, int f, int ld, double lambda, floa
                                   150 * 1024 + 16);
         attr_set = true;
     }
-    WmfProfScope ps(WMF_SLOT_FACTORIZE, st);
+    WmfProfScope ps("factorize_kernel", st);
     if (use_lds)
         hipLaunchKernelGGL(factorize_kernel<true>, dim3(1), dim3(256), bytes + 16, st, G_sum, f, ld, lambda, Wwhite, Wunwhite,
                            info, gA);
@@ -949,8 +949,9 @@ static void launch_transform6(const float* in, int64_t m, int f, int ld, const f
         (void)hipFuncSetAttribute((const void*)transform6_kernel<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((transform6_kernel<NFB>), dim3((unsigned)grid), dim3(512), lds, st, in, m, f, ld, W, set_col0_one, out,
-                       col0_out, nblk);
+    static const char* nm = wmf_kname("transform6_kernel<%d>", NFB);
+    WMF_LAUNCH(nm, (transform6_kernel<NFB>), dim3((unsigned)grid), dim3(512), lds, st, in, m, f, ld, W, set_col0_one, out,
+               col0_out, nblk);
 }
 
 template <int NFB, int NB0, int NBW>
@@ -964,8 +965,9 @@ static void launch_transform_slice(const float* in, int64_t m, int f, int ld, co
                                   (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((transform_kernel<NFB, true, NB0, NBW>), dim3((unsigned)grid), dim3(512), lds, st, in, m, f, ld, W,
-                       set_col0_one, out, col0_out, nblk);
+    static const char* nm = wmf_kname("transform_kernel<%d, true, %d, %d>", NFB, NB0, NBW);
+    WMF_LAUNCH(nm, (transform_kernel<NFB, true, NB0, NBW>), dim3((unsigned)grid), dim3(512), lds, st, in, m, f, ld, W,
+               set_col0_one, out, col0_out, nblk);
 }
 
 template <int NFB>
@@ -998,8 +1000,9 @@ static void launch_transform_nfb(const float* in, int64_t m, int f, int ld, cons
             launch_transform_slice<NFB, 12, NFB - 12>(in, m, f, ld, W, set_col0_one, out, col0_out, grid, nblk, st);
         }
     } else {
-        hipLaunchKernelGGL((transform_kernel<NFB, false>), dim3((unsigned)grid), dim3(512), 0, st, in, m, f, ld, W,
-                           set_col0_one, out, col0_out, nblk);
+        static const char* nm = wmf_kname("transform_kernel<%d, false, 0, %d>", NFB, NFB);
+        WMF_LAUNCH(nm, (transform_kernel<NFB, false>), dim3((unsigned)grid), dim3(512), 0, st, in, m, f, ld, W,
+                   set_col0_one, out, col0_out, nblk);
     }
 }
 
@@ -1007,7 +1010,6 @@ int wmf_launch_transform(const float* in, int64_t m, int f, int ld, const float*
                          float* col0_out, hipStream_t st) {
     if (m <= 0) return 0;
     const int nfb = (f + 15) / 16;
-    WmfProfScope ps(WMF_SLOT_TRANSFORM, st);
     switch (nfb) {
 #define C(N) case N: launch_transform_nfb<N>(in, m, f, ld, W, set_col0_one, out, col0_out, st); break;
         C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)

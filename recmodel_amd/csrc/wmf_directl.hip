@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             else if (younger == 1) dl_wait_vm<NI>();
             else if (itn < count) dl_wait_vm<2>();       // only the next row's two metadata requests are younger
             else dl_wait_vm<0>();
-            if (dbg & 2) return;
+            if (WMF_ABL(dbg, 2)) return;
             const unsigned par = ((mb + (G >> 2)) & 3) * 256;
             const int nk = min(4, (d - 16 * G + 3) >> 2);        // k-steps of this group that hold entries of the row
             // LDS operands of k-step t + 1 are requested before the MFMAs of k-step t (only the first k-step of a group
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
                 issue_rows(std::integral_constant<int, S>{}, G + 4, mb);
                 if (G + 5 < ngroups) issue_rows(std::integral_constant<int, S + 1>{}, G + 5, mb);
             }
-            if (dbg & 2) return;
+            if (WMF_ABL(dbg, 2)) return;
             // right-hand side and border on the VALU from the raw values; MFMA operands scaled by sqrt(w) and split.
             // Block column by block column: the split of column bj + 1 (VALU) has no dependence on the MFMAs of column bj,
             // and a bf16 MFMA leaves half of its cycles to the VALU.
@@ -409,8 +409,8 @@ int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const
     const dim3 grid((unsigned)(count < cap ? count : cap));
     const int dbg = wmf_debug_flags;
     const bool x6 = !(dbg & 8192);                              // debug flag 8192: f32 MFMA accumulation
-#define DL_LAUNCH(N, B, X) hipLaunchKernelGGL((solve_directl_kernel<N, B, X>), grid, dim3(64), DL_LDSB(N), st, rows, count, V, indptr, \
-                                              indices, vals, f, ld, g, fb_rows, fb_count, dbg)
+#define DL_LAUNCH(N, B, X) WMF_LAUNCH("solve_directl_kernel<" #N ", " #B ", " #X ">", (solve_directl_kernel<N, B, X>), grid, dim3(64), \
+                                      DL_LDSB(N), st, rows, count, V, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg)
 #define DL_PICK(N) do { if (f % 16) { if (x6) DL_LAUNCH(N, true, true); else DL_LAUNCH(N, true, false); } \
                         else        { if (x6) DL_LAUNCH(N, false, true); else DL_LAUNCH(N, false, false); } } while (0)
     if (nfb == 4) DL_PICK(4); else DL_PICK(8);

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
         auto step = [&](auto slot, int G) {
             constexpr int S = decltype(slot)::value;
             if (G >= ngroups) return;
-            if (!(dbg & 2)) {
+            if (!WMF_ABL(dbg, 2)) {
 #pragma unroll
                 for (int t = 0; t < GS; ++t) {
                     float fw[NFB];
@@ -286,19 +286,23 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
     // (f = 64 / 65 can run there too, debug flag 65536, but gains nothing: cfg2 item side 1.34 ms against 1.30 here)
     if (normal > 0 && biasv == nullptr && wmf_directl_supported(f, ld) && !(dbg & 4096) && (f >= 128 || (dbg & 65536))) {
         (void)wmf_launch_directl(rows, normal, V, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, st);
-    } else if (normal > 0)
-        hipLaunchKernelGGL((solve_directw_kernel<NFB, 0, BORDER>), dim3((unsigned)(normal < cap ? normal : cap)), dim3(64), 0, st,
-                           rows, normal, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
-                           nullptr, nullptr, nullptr, nullptr, 1, 0);
+    } else if (normal > 0) {
+        static const char* nm = wmf_kname("solve_directw_kernel<%d, 0, %s>", NFB, BORDER ? "true" : "false");
+        WMF_LAUNCH(nm, (solve_directw_kernel<NFB, 0, BORDER>), dim3((unsigned)(normal < cap ? normal : cap)), dim3(64), 0, st,
+                   rows, normal, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
+                   nullptr, nullptr, nullptr, nullptr, 1, 0);
+    }
     if (pl->heavy_count > 0) {
         const int64_t nseg = pl->seg_total;
-        hipLaunchKernelGGL((solve_directw_kernel<NFB, 1, BORDER>), dim3((unsigned)(nseg < cap ? nseg : cap)), dim3(64), 0, st, rows,
-                           nseg, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg, pl->seg_lo,
-                           pl->seg_d, pl->seg_first, pl->partial, 1, 0);
+        static const char* nm1 = wmf_kname("solve_directw_kernel<%d, 1, %s>", NFB, BORDER ? "true" : "false");
+        static const char* nm2 = wmf_kname("solve_directw_kernel<%d, 2, %s>", NFB, BORDER ? "true" : "false");
+        WMF_LAUNCH(nm1, (solve_directw_kernel<NFB, 1, BORDER>), dim3((unsigned)(nseg < cap ? nseg : cap)), dim3(64), 0, st, rows,
+                   nseg, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg, pl->seg_lo,
+                   pl->seg_d, pl->seg_first, pl->partial, 1, 0);
         const int64_t nh = pl->heavy_count;
-        hipLaunchKernelGGL((solve_directw_kernel<NFB, 2, BORDER>), dim3((unsigned)(nh < cap ? nh : cap)), dim3(64), 0, st,
-                           rows + normal, nh, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
-                           pl->seg_lo, pl->seg_d, pl->seg_first, pl->partial, 1, 0);
+        WMF_LAUNCH(nm2, (solve_directw_kernel<NFB, 2, BORDER>), dim3((unsigned)(nh < cap ? nh : cap)), dim3(64), 0, st,
+                   rows + normal, nh, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
+                   pl->seg_lo, pl->seg_d, pl->seg_first, pl->partial, 1, 0);
     }
 }
 
@@ -309,17 +313,19 @@ static void launch_accumulate_nfb(const float* V, const int64_t* indptr, const i
                                   const float* vals, int64_t n, int f, int ld, float* partial, int slot_stride, int slot_offset,
                                   hipStream_t st) {
     const int64_t cap = 256 * 4 * DwCfg<NFB>::OCC * 3;
-    hipLaunchKernelGGL((solve_directw_kernel<NFB, 1, BORDER>), dim3((unsigned)(n < cap ? n : cap)), dim3(64), 0, st, nullptr, n, V,
-                       nullptr, indptr, indices, vals, f, ld, nullptr, nullptr, nullptr, wmf_debug_flags & ~3, indptr, degrees,
-                       nullptr, partial, slot_stride, slot_offset);
+    static const char* nm = wmf_kname("solve_directw_kernel<%d, 1, %s>", NFB, BORDER ? "true" : "false");
+    WMF_LAUNCH(nm, (solve_directw_kernel<NFB, 1, BORDER>), dim3((unsigned)(n < cap ? n : cap)), dim3(64), 0, st, nullptr, n, V,
+               nullptr, indptr, indices, vals, f, ld, nullptr, nullptr, nullptr, wmf_debug_flags & ~3, indptr, degrees,
+               nullptr, partial, slot_stride, slot_offset);
 }
 template <int NFB, bool BORDER>
 static void launch_eliminate_nfb(float* partial, int64_t n, int slots_per_row, int f, int ld, float* g, int32_t* fb_rows,
                                  int32_t* fail_count, hipStream_t st) {
     const int64_t cap = 256 * 4 * DwCfg<NFB>::OCC * 3;
-    hipLaunchKernelGGL((solve_directw_kernel<NFB, 2, BORDER>), dim3((unsigned)(n < cap ? n : cap)), dim3(64), 0, st, nullptr, n,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, f, ld, g, fb_rows, fail_count, wmf_debug_flags & ~3, nullptr,
-                       nullptr, nullptr, partial, slots_per_row, 0);
+    static const char* nm = wmf_kname("solve_directw_kernel<%d, 2, %s>", NFB, BORDER ? "true" : "false");
+    WMF_LAUNCH(nm, (solve_directw_kernel<NFB, 2, BORDER>), dim3((unsigned)(n < cap ? n : cap)), dim3(64), 0, st, nullptr, n,
+               nullptr, nullptr, nullptr, nullptr, nullptr, f, ld, g, fb_rows, fail_count, wmf_debug_flags & ~3, nullptr,
+               nullptr, nullptr, partial, slots_per_row, 0);
 }
 static bool dw_border(int f) { return f > 16 && f % 16 == 1 && (f / 16) % 4 != 3 && !(wmf_debug_flags & 256); }
 

@@ -8,6 +8,7 @@
 // load - select - store by ALL lanes, and the lanes that share an address then race with the one real writer.
 #pragma once
 #include "wmf_common.h"
+#include "wmf_internal.h"
 
 template <int NFB>
 __device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for bj = bi .. NFB - 1"
@@ -27,7 +28,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
                                              int q, const int (&baddr)[4], int dbg, float (&gb)[NFB], float& tb, bool& ok) {
     float wvs[WREG ? NFB : 1][4], wbs[(WREG && BORDER) ? NFB : 1][4];
     // ---- C: block elimination, everything in registers except the two panel buffers
-    if (!(dbg & 1)) {
+    if (!WMF_ABL(dbg, 1)) {
 #pragma unroll
         for (int b = 0; b < NFB; ++b) {
 #pragma unroll
@@ -44,7 +45,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
             // ids the compiler cannot see through make it compare in place: 20 v_cmp per pivot instead.
             int rp = r, qp = q;
             asm volatile("" : "+v"(rp), "+v"(qp));
-            if (!(dbg & 8))                                      // timing experiments only: 8 = no tile inverse
+            if (!WMF_ABL(dbg, 8))                                      // timing experiments only: 8 = no tile inverse
                 gj_inv_sweep<GJ_LDS, true>(X, baddr, rp, qp, ok, std::make_integer_sequence<int, 16>{});
 #else
             gj_inv_sweep<GJ_LDS, true>(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
@@ -127,7 +128,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
         if (!(piv > 1e-20f)) ok = false;
         tb = eacc * __builtin_amdgcn_rcpf(piv);
     }
-    if (!(dbg & 1)) {
+    if (!WMF_ABL(dbg, 1)) {
 #pragma unroll
         for (int p = NFB - 1; p >= 0; --p) {
             float s[4] = {0.f, 0.f, 0.f, 0.f};

@@ -40,7 +40,7 @@ int wmf_launch_predict(const float* users, const float* items, int f, int ld, in
     if (n <= 0) return 0;
     int64_t grid = (n + 15) / 16;
     if (grid > 8192) grid = 8192;
-    WmfProfScope ps(WMF_SLOT_PREDICT, st);
+    WmfProfScope ps("predict_kernel", st);
     hipLaunchKernelGGL(predict_kernel, dim3((unsigned)grid), dim3(256), 0, st, users, items, ld, bias, ui, n_u, ii, n_i,
                        n, out);
     return 0;
@@ -97,10 +97,9 @@ int wmf_launch_eval(const float* users, const float* items, int f, int ld, int b
     int64_t grid = (n + 3) / 4;
     if (grid > WMF_EVAL_MAX_BLOCKS) grid = WMF_EVAL_MAX_BLOCKS;
     if (grid < 1) grid = 1;
-    WmfProfScope ps(WMF_SLOT_EVAL, st);
-    hipLaunchKernelGGL(eval_kernel, dim3((unsigned)grid), dim3(256), 0, st, users, items, ld, bias, indptr, indices,
-                       values, n, partial);
-    hipLaunchKernelGGL(eval_finish_kernel, dim3(1), dim3(64), 0, st, partial, (int)grid, out3);
+    WMF_LAUNCH("eval_kernel", eval_kernel, dim3((unsigned)grid), dim3(256), 0, st, users, items, ld, bias, indptr, indices,
+               values, n, partial);
+    WMF_LAUNCH("eval_finish_kernel", eval_finish_kernel, dim3(1), dim3(64), 0, st, partial, (int)grid, out3);
     return 0;
 }
 
@@ -116,7 +115,7 @@ int wmf_launch_confidence(float* values, int64_t nnz, double alpha, double beta,
     if (nnz <= 0) return 0;
     int64_t grid = (nnz + 255) / 256;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(confidence_kernel, dim3((unsigned)grid), dim3(256), 0, st, values, nnz, (float)alpha, (float)beta,
-                       mode);
+    WMF_LAUNCH("confidence_kernel", confidence_kernel, dim3((unsigned)grid), dim3(256), 0, st, values, nnz, (float)alpha,
+               (float)beta, mode);
     return 0;
 }

@@ -16,20 +16,21 @@ struct wmf_plan {
     int64_t n;                 // rows
     int f;
     int64_t count[WMF_NBINS];  // rows per bin
-    int64_t count8;            // rows of the first bin with at most 8 entries; they come first in rows[WMF_BIN_LOW16]
+    int64_t count8, nnz8;      // rows of the first bin with at most 8 entries (and their entries); they come first in rows[WMF_BIN_LOW16]
+    bool bias;                 // created for a biased model: w_eff is allocated
     int64_t nnz[WMF_NBINS];    // stored entries per bin
     int32_t* rows[WMF_NBINS];  // device: row ids of each bin (slices of rows_all)
     int32_t* rows_all;         // device: n row ids grouped by bin
     int32_t* fallback_rows;    // device: n slots, rows bounced to the general kernel at run time
     int32_t* fallback_count;   // device: 1 counter
-    float* w_eff;              // device: nnz effective weights (values - bias[indices]), allocated on first biased solve
+    float* w_eff;              // device: nnz effective weights (values - bias[indices]) of a biased model
     // rows of the MFMA bin with more than WMF_HEAVY_T entries sit at the end of that bin and are split into segments
     int64_t heavy_count, seg_total;
     int64_t* seg_lo;           // device: first entry of each segment
     int32_t* seg_d;            // device: entries in each segment
     int32_t* seg_first;        // device: heavy_count + 1 prefix of segment counts
     float* partial;            // device: seg_total x (tiles x 256) partial accumulators
-    float* wide_ws;            // device: workspace of the f > 144 pivoted-LU fallback, allocated on first use
+    float* wide_ws;            // device: workspace of the f > 144 pivoted-LU fallback
 };
 
 int wmf_gram_max_waves(int f);
@@ -44,10 +45,7 @@ int wmf_launch_transform(const float* in, int64_t m, int f, int ld, const float*
 int wmf_launch_solve(const wmf_plan* plan, const float* V, const float* bias_fixed, const int64_t* indptr,
                      const int32_t* indices, const float* values, int f, int ld, float* g, int32_t* fail_count,
                      hipStream_t st);
-int wmf_direct_supported(int f);
-int wmf_launch_direct(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
-                      const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
-                      int32_t* fb_count, hipStream_t st);
+static inline int wmf_direct_supported(int f) { return f >= 1 && f <= 144; }   // one wave per row holds the f x f system
 // wmf_directl.hip: normal heavy rows at f = 128 / 129 through an LDS-DMA row ring
 int wmf_directl_supported(int f, int ld);
 int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const int64_t* indptr, const int32_t* indices,
@@ -62,9 +60,6 @@ int wmf_launch_eliminate(float* partial, int64_t n, int slots_per_row, int f, in
                          int32_t* fail_count, hipStream_t st);
 void wmf_launch_bias_adjust(const float* vals, const int32_t* indices, const float* biasv, int64_t nnz, float* w_eff,
                             hipStream_t st);
-int wmf_launch_direct64(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
-                        const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
-                        int32_t* fb_count, hipStream_t st);
 int wmf_wide_supported(int f);
 int wmf_launch_wide(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                     const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
@@ -98,18 +93,28 @@ int wmf_launch_rank_batch(const float* users, const float* items, int f, int ld,
 int wmf_launch_confidence(float* values, int64_t nnz, double alpha, double beta, int mode, hipStream_t st);
 
 void wmf_set_error(const char* fmt, ...);
-extern int wmf_debug_flags;   // timing experiments only (tools/kernel_lab.py); 0 in normal use
+extern int wmf_debug_flags;   // kernel-selection switches for timing experiments (tools/kernel_lab.py); 0 in normal use
+// Ablation switches whose results are WRONG (1 no elimination, 2 no accumulation MFMAs, 8 no tile inverse) are compiled
+// into a -DWMF_LAB build only (tools/build_variant.sh); the shipped library has no such code path.
+#ifdef WMF_LAB
+#define WMF_ABL(dbg, bits) ((dbg) & (bits))
+#else
+#define WMF_ABL(dbg, bits) 0
+#endif
 
-// per-kernel event timing (wmf_api.hip)
-enum {
-    WMF_SLOT_GRAM = 0, WMF_SLOT_GRAM_REDUCE, WMF_SLOT_FACTORIZE, WMF_SLOT_TRANSFORM, WMF_SLOT_SOLVE_LOW16,
-    WMF_SLOT_SOLVE_LOW32, WMF_SLOT_SOLVE_HEAVY, WMF_SLOT_SOLVE_FALLBACK, WMF_SLOT_EVAL, WMF_SLOT_PREDICT,
-    WMF_SLOT_OTHER, WMF_SLOT_SOLVE_DIRECT
-};
-void wmf_prof_begin(int slot, hipStream_t st);
+// per-kernel event timing (wmf_api.hip).  A launch site names its kernel the way rocprofv3 prints the symbol, up to and
+// including the template arguments ("solve_low_kernel<9, 1, false, false>"), so that bench.py's table and a
+// rocprofv3 --kernel-trace --stats summary of the same run can be matched line by line.
+const char* wmf_kname(const char* fmt, ...);     // interned: the pointer stays valid for the life of the library
+void wmf_prof_begin(const char* name, hipStream_t st);
 void wmf_prof_end(hipStream_t st);
 struct WmfProfScope {
     hipStream_t st;
-    WmfProfScope(int slot, hipStream_t s) : st(s) { wmf_prof_begin(slot, s); }
+    WmfProfScope(const char* name, hipStream_t s) : st(s) { wmf_prof_begin(name, s); }
     ~WmfProfScope() { wmf_prof_end(st); }
 };
+#define WMF_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS, ST, ...)                          \
+    do {                                                                             \
+        WmfProfScope wmf_ps_(NAME, ST);                                              \
+        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, ST, __VA_ARGS__);               \
+    } while (0)

@@ -142,7 +142,7 @@ int wmf_launch_rank_batch(const float* users, const float* items, int f, int ld,
     int64_t grid = (tiles + 3) / 4;
     if (grid > 16384) grid = 16384;
     {
-        WmfProfScope ps(WMF_SLOT_PREDICT, st);
+        WmfProfScope ps("score_tile_kernel", st);
         hipLaunchKernelGGL(score_tile_kernel, dim3((unsigned)grid), dim3(256), 0, st, users, items, ld, bias, user_idx, nu, cand, nc,
                            scores);
     }
@@ -164,7 +164,7 @@ int wmf_launch_hits(const float* users, const float* items, int ld, int bias, co
     if (n_pairs <= 0) return 0;
     int64_t grid = (n_pairs + 3) / 4;
     if (grid > 16384) grid = 16384;
-    WmfProfScope ps(WMF_SLOT_PREDICT, st);
+    WmfProfScope ps("hit_kernel", st);
     hipLaunchKernelGGL(hit_kernel, dim3((unsigned)grid), dim3(256), 0, st, users, items, ld, bias, pair_user, pair_item, pair_row,
                        n_pairs, cand, n_cand, slot, topn, n_topn, reinterpret_cast<unsigned long long*>(hits));
     return 0;

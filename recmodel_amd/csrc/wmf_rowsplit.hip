@@ -150,7 +150,7 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
             const float* vb = Vs + (c & 1) * (C::RC * C::LDV);
             const float* wb = wsm + (c & 1) * C::RC;
             const float* pb = psm + (c & 1) * C::RC;
-            const int nsteps = (dbg & 2) ? 0 : (nrow + 3) >> 2;  // dbg: timing ablations (wmf_debug_set_flags)
+            const int nsteps = WMF_ABL(dbg, 2) ? 0 : (nrow + 3) >> 2;  // dbg: timing ablations (wmf_debug_set_flags)
             for (int ks = 0; ks < nsteps; ++ks) {
                 const float wq = wb[4 * ks + q], pq = pb[4 * ks + q];
                 const float* vrow = vb + (4 * ks + q) * C::LDV + r;
@@ -246,7 +246,7 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
             }
             (void)p;
         };
-        if (!(dbg & 1)) {
+        if (!WMF_ABL(dbg, 1)) {
 #pragma unroll 1
             for (int p = 0; p < NFB; ++p) {
                 float* P1 = Pan;                                 // originals of block row p
@@ -374,8 +374,9 @@ static void launch_rowsplit_nfb(const int32_t* rows, int64_t count, const float*
     }
     int64_t grid = 256 * 2 * 2;                                  // two resident workgroups per CU, two rounds
     if (grid > count) grid = count;
-    hipLaunchKernelGGL((solve_rowsplit_kernel<NFB, BORDER>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, rows, count, V, biasv,
-                       indptr, indices, vals, f, ld, g, fb_rows, fb_count, wmf_debug_flags);
+    static const char* nm = wmf_kname("solve_rowsplit_kernel<%d, %s>", NFB, BORDER ? "true" : "false");
+    WMF_LAUNCH(nm, (solve_rowsplit_kernel<NFB, BORDER>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, rows, count, V, biasv,
+               indptr, indices, vals, f, ld, g, fb_rows, fb_count, wmf_debug_flags);
 }
 
 // 144 < f <= 256, and f = 16 m + 1 up to 257 (k = 16 m with biases: m blocks and a border column)

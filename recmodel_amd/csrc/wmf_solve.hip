@@ -596,7 +596,7 @@ int wmf_launch_spmm(const float* V, const int64_t* indptr, const int32_t* indice
     if (n <= 0) return 0;
     int64_t grid = (n + 3) / 4;
     if (grid > 8192) grid = 8192;
-    WmfProfScope ps(WMF_SLOT_OTHER, st);
+    WmfProfScope ps("spmm_kernel", st);
     hipLaunchKernelGGL(spmm_kernel, dim3((unsigned)grid), dim3(256), 0, st, V, indptr, indices, values, n, ld, g);
     return 0;
 }
@@ -624,7 +624,7 @@ void wmf_launch_bias_adjust(const float* vals, const int32_t* indices, const flo
     if (nnz <= 0) return;
     int64_t grid = (nnz + 255) / 256;
     if (grid > 8192) grid = 8192;
-    WmfProfScope ps(WMF_SLOT_OTHER, st);
+    WmfProfScope ps("bias_adjust_kernel", st);
     const bool aligned = ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(indices)) & 15) == 0;
     hipLaunchKernelGGL(bias_adjust_kernel, dim3((unsigned)grid), dim3(256), 0, st, vals, indices, biasv, nnz,
                        aligned ? (nnz >> 2) : (int64_t)0, w_eff);
@@ -638,19 +638,25 @@ static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, c
     // rows with at most 8 entries come first in the bin and go two per wave (solve_pair_kernel)
     const int64_t c8 = (wmf_debug_flags & 2048) ? 0 : pl->count8;
     if (c8 > 0) {
-        WmfProfScope ps(WMF_SLOT_SOLVE_LOW16, st);
+        static const char* nm = wmf_kname("solve_pair_kernel<%d>", NCH);
+        WmfProfScope ps(nm, st);
         hipLaunchKernelGGL((solve_pair_kernel<NCH>), dim3((unsigned)(((c8 + 1) / 2 + 3) / 4)), dim3(256), 0, st,
                            pl->rows[WMF_BIN_LOW16], c8, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
                            pl->fallback_count);
     }
     if (c0 - c8 > 0) {
-        WmfProfScope ps(WMF_SLOT_SOLVE_LOW16, st);
+        static const char* nm = wmf_kname("solve_low_kernel<%d, 1, false, false>", NCH);
+        WmfProfScope ps(nm, st);
         hipLaunchKernelGGL((solve_low_kernel<NCH, 1, false>), dim3((unsigned)((c0 - c8 + 3) / 4)), dim3(256), 0, st,
                            pl->rows[WMF_BIN_LOW16] + c8, c0 - c8, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
                            pl->fallback_count);
     }
     if (c1 > 0) {
-        WmfProfScope ps(WMF_SLOT_SOLVE_LOW32, st);
+        static const char* nm_gj = wmf_kname("solve_low_kernel<%d, 2, false, false>", NCH);
+        static const char* nm_x6 = wmf_kname("solve_low_kernel<%d, 2, true, true>", NCH);
+        static const char* nm_blk = wmf_kname("solve_low_kernel<%d, 2, true, false>", NCH);
+        const bool x6 = NCH % 2 == 0 && ld % 32 == 0 && !(wmf_debug_flags & 524288);
+        WmfProfScope ps((wmf_debug_flags & 64) ? nm_gj : (x6 ? nm_x6 : nm_blk), st);
         if (wmf_debug_flags & 64)       // plain 32 x 32 Gauss-Jordan, kept for A/B timing
             hipLaunchKernelGGL((solve_low_kernel<NCH, 2, false>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
                                pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
@@ -679,8 +685,9 @@ static void launch_general(const int32_t* rows, int64_t count, const int32_t* co
                                   (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((solve_general_kernel<NFB>), dim3(grid), dim3(256), lds, st, rows, count, count_ptr, V, biasv,
-                       indptr, indices, vals, f, ld, g, fail_count);
+    static const char* nm = wmf_kname("solve_general_kernel<%d>", NFB);
+    WMF_LAUNCH(nm, (solve_general_kernel<NFB>), dim3(grid), dim3(256), lds, st, rows, count, count_ptr, V, biasv,
+               indptr, indices, vals, f, ld, g, fail_count);
 }
 
 static int dispatch_general(const int32_t* rows, int64_t count, const int32_t* count_ptr, int grid, const float* V,
@@ -703,10 +710,8 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
     if (nnz == 0)                                                      // nothing stored: every row solves to zero
         return hipMemsetAsync(g, 0, (size_t)pl->n * ld * sizeof(float), st) == hipSuccess ? 0 : -2;
     if (biasv) {                                                       // fold the fixed side's biases into the weights once
-        wmf_plan* plm = const_cast<wmf_plan*>(pl);
-        if (!plm->w_eff && hipMalloc((void**)&plm->w_eff, (size_t)nnz * sizeof(float)) != hipSuccess) return -2;
-        wmf_launch_bias_adjust(vals, indices, biasv, nnz, plm->w_eff, st);
-        vals = plm->w_eff;
+        wmf_launch_bias_adjust(vals, indices, biasv, nnz, pl->w_eff, st);   // (w_eff: allocated by wmf_plan_create(bias = 1))
+        vals = pl->w_eff;
         biasv = nullptr;
     }
     switch ((ld + 15) / 16) {
@@ -717,25 +722,12 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
     }
     const bool general_ok = f <= 144;
     if (pl->count[WMF_BIN_MFMA] > 0) {
-        WmfProfScope ps(WMF_SLOT_SOLVE_DIRECT, st);
-        // One wave per row with the whole system in MFMA accumulator registers (wmf_directw.hip).  Debug flags
-        // select the two earlier designs, kept for A/B timing: 16 = workgroup per row (wmf_direct.hip),
-        // 128 = one wave per row with an LDS image of the matrix (wmf_direct64.hip, f <= 64 only).
-        int rc;
-        if (wmf_debug_flags & 16)
-            rc = wmf_launch_direct(pl->rows[WMF_BIN_MFMA], pl->count[WMF_BIN_MFMA], V, biasv, indptr, indices, vals, f, ld, g,
-                                   pl->fallback_rows, pl->fallback_count, st);
-        else if (f <= 64 && (wmf_debug_flags & 128))
-            rc = wmf_launch_direct64(pl->rows[WMF_BIN_MFMA], pl->count[WMF_BIN_MFMA], V, biasv, indptr, indices, vals, f, ld, g,
-                                     pl->fallback_rows, pl->fallback_count, st);
-        else
-            rc = wmf_launch_directw(pl, V, biasv, indptr, indices, vals, f, ld, g, st);
-        if (rc) return -1;
+        // one wave per row with the whole system in MFMA accumulator registers (wmf_directw.hip, wmf_directl.hip)
+        if (wmf_launch_directw(pl, V, biasv, indptr, indices, vals, f, ld, g, st)) return -1;
     }
     if (pl->count[WMF_BIN_GENERAL] > 0) {
         // f > 144: rows with more than 32 entries go to the workgroup-per-row kernel (wmf_wide.hip)
         if (!wmf_wide_supported(f)) return -1;
-        WmfProfScope ps(WMF_SLOT_SOLVE_HEAVY, st);
         // f <= 256: four waves per row, tiles owned by block row (wmf_rowsplit.hip); f = 257 .. 272, or debug flag
         // 1024: the run-time-indexed eight-wave kernel (wmf_wide.hip)
         if (wmf_rowsplit_supported(f) && !(wmf_debug_flags & 1024)) {
@@ -746,15 +738,12 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
     }
     {
         // rows bounced by the other kernels (negative weights / not positive definite); count is on the device
-        WmfProfScope ps(WMF_SLOT_SOLVE_FALLBACK, st);
         if (general_ok) {
             if (dispatch_general(pl->fallback_rows, 0, pl->fallback_count, 256, V, biasv, indptr, indices, vals, f, ld, g,
                                  fail_count, st)) return -1;
         } else {
-            wmf_plan* plm = const_cast<wmf_plan*>(pl);
-            if (!plm->wide_ws && hipMalloc((void**)&plm->wide_ws, wmf_wide_lu_workspace_bytes(f)) != hipSuccess) return -2;
             if (wmf_launch_wide_lu(pl->fallback_rows, pl->fallback_count, V, biasv, indptr, indices, vals, f, ld, g, fail_count,
-                                   plm->wide_ws, st)) return -1;
+                                   pl->wide_ws, st)) return -1;
         }
     }
     return 0;

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512, 1) void solve_wide_kernel(const int32_t* __res
             __syncthreads();
             if (c + 2 < nchunks) load_chunk(pre, wpre, lo, d, base + 2 * C::RC);
             else if (itn < count) load_chunk(pre, wpre, lon, dn, slot * C::RC);
-            const int nsteps = (dbg & 2) ? 0 : (nrow + 3) >> 2;           // dbg: timing ablations (wmf_debug_set_flags)
+            const int nsteps = WMF_ABL(dbg, 2) ? 0 : (nrow + 3) >> 2;           // dbg: timing ablations (wmf_debug_set_flags)
             for (int s = 0; s < nsteps; ++s) {
                 const float wq = wsm[4 * s + q];
                 const float pb = (r == 0) ? psm[4 * s + q] : 0.f;          // rhs tile: p in column 0
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512, 1) void solve_wide_kernel(const int32_t* __res
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) baddr[kq] = (r + 16 * kq) * 4;
 #pragma unroll 1
-        for (int p = 0; p < ((dbg & 1) ? 0 : NFB); ++p) {
+        for (int p = 0; p < (WMF_ABL(dbg, 1) ? 0 : NFB); ++p) {
             // (a) the wave that owns tile (p, p) inverts it in registers: a symmetric tile in accumulator layout is
             //     the row-distributed layout of the Gauss-Jordan sweep (wmf_common.h), 16 DPP steps, no other wave waits
             //     on a serial Cholesky.  X goes to T[p] as [row][col] for everybody's A operand.
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void solve_wide_kernel(const int32_t* __res
         // ---- D. g_p = w_p - sum_{j > p} W_pj g_j, column by column: once g_p is final every tile (i, p), i < p, takes
         //      its product out of z_i -- one tile, hence one writer, per block i and step
 #pragma unroll 1
-        for (int p = ((dbg & 1) ? -1 : NFB - 1); p >= 0; --p) {
+        for (int p = (WMF_ABL(dbg, 1) ? -1 : NFB - 1); p >= 0; --p) {
             const float gp = zb[16 * p + r];                     // final: all columns j > p have been taken out
 #pragma unroll
             for (int a = 0; a < C::NACC; ++a) {
@@ -369,8 +369,9 @@ static void launch_wide_nfb(const int32_t* rows, int64_t count, const float* V, 
     }
     int64_t grid = 256 * 2;                                      // one resident workgroup per CU (LDS), two rounds
     if (grid > count) grid = count;
-    hipLaunchKernelGGL((solve_wide_kernel<NFB>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, rows, count, V, biasv, indptr,
-                       indices, vals, f, ld, g, fb_rows, fb_count, wmf_debug_flags);
+    static const char* nm = wmf_kname("solve_wide_kernel<%d>", NFB);
+    WMF_LAUNCH(nm, (solve_wide_kernel<NFB>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, rows, count, V, biasv, indptr,
+               indices, vals, f, ld, g, fb_rows, fb_count, wmf_debug_flags);
 }
 
 int wmf_wide_supported(int f) { return f > 144 && f <= 272; }
@@ -394,7 +395,7 @@ int wmf_launch_wide_lu(const int32_t* rows, const int32_t* count_ptr, const floa
                        const int64_t* indptr, const int32_t* indices, const float* vals, int f, int ld, float* g,
                        int32_t* fail_count, float* work, hipStream_t st) {
     if (f > 272 || ld > 276) return -1;
-    hipLaunchKernelGGL(solve_wide_lu_kernel, dim3(WMF_WIDE_LU_GRID), dim3(256), 0, st, rows, count_ptr, V, biasv, indptr,
-                       indices, vals, f, ld, g, fail_count, work);
+    WMF_LAUNCH("solve_wide_lu_kernel", solve_wide_lu_kernel, dim3(WMF_WIDE_LU_GRID), dim3(256), 0, st, rows, count_ptr, V, biasv,
+               indptr, indices, vals, f, ld, g, fail_count, work);
     return 0;
 }

@@ -88,10 +88,10 @@ class HipKernels:
         _lib.check(self.lib.wmf_row_transform(_ptr(inp), m, f, ld, _ptr(W), int(set_col0_one), _ptr(out), _ptr(col0_out),
                                               _stream()))
 
-    def plan_create(self, indptr_host, n, f):
+    def plan_create(self, indptr_host, n, f, bias):
         handle = ctypes.c_void_p()
-        _lib.check(self.lib.wmf_plan_create(indptr_host.ctypes.data_as(ctypes.c_void_p), n, f, ctypes.byref(handle)))
-        stats = np.zeros(8, dtype=np.int64)
+        _lib.check(self.lib.wmf_plan_create(indptr_host.ctypes.data_as(ctypes.c_void_p), n, f, int(bool(bias)), ctypes.byref(handle)))
+        stats = np.zeros(10, dtype=np.int64)
         _lib.check(self.lib.wmf_plan_stats(handle, stats.ctypes.data_as(ctypes.c_void_p)))
         return handle, stats
 
@@ -129,7 +129,7 @@ class HipKernels:
 class Csr:
     """CSR shard resident in HBM (int64 indptr, int32 indices, fp32 values) plus its row plan."""
 
-    def __init__(self, kernels, indptr, indices, values, n_cols, f):
+    def __init__(self, kernels, indptr, indices, values, n_cols, f, bias=False):
         self.kernels = kernels
         self.indptr = indptr.to(torch.int64).contiguous()
         self.indices = indices.to(torch.int32).contiguous()
@@ -139,8 +139,9 @@ class Csr:
         self.nnz = int(self.indices.numel())
         self.f = f
         host_ptr = np.ascontiguousarray(self.indptr.cpu().numpy(), dtype=np.int64)
-        self._plan, stats = kernels.plan_create(host_ptr, self.n_rows, f)
-        self.bin_rows, self.bin_nnz = stats[:4].copy(), stats[4:].copy()
+        self._plan, stats = kernels.plan_create(host_ptr, self.n_rows, f, bias)
+        self.bin_rows, self.bin_nnz = stats[:4].copy(), stats[4:8].copy()
+        self.rows8, self.nnz8 = int(stats[8]), int(stats[9])           # rows of bin 0 with at most 8 entries
 
     def __del__(self):
         plan, self._plan = getattr(self, "_plan", None), None
@@ -158,6 +159,8 @@ def coo_to_csr(rows, cols, vals, n_rows):
     order = torch.argsort(key, stable=True)
     rows_s = rows[order]
     counts = torch.bincount(rows_s, minlength=n_rows)
+    if counts.numel() != n_rows:          # a row id >= n_rows: cumsum(out=) below would silently resize indptr
+        raise IndexError(f"row index {int(rows_s.max().item())} is out of bounds for {n_rows} rows")
     indptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=rows.device)
     torch.cumsum(counts, 0, out=indptr[1:])
     return indptr, cols[order].to(torch.int32), vals[order]
@@ -277,6 +280,20 @@ class AlsEngine:
         return "items" if side == "users" else "users"
 
     # ---------------------------------------------------------------- data
+    def _check_csr(self, indptr, cols, what):
+        """The reference indexes the fixed factors with the stored column ids (wmf_model.py:233 ``Y[idx, :]``) and raises
+        IndexError for an id outside them; here the ids become gather positions of device kernels, so they are checked once,
+        when the matrix is handed over."""
+        if indptr.numel() != self.n["users"] + 1:
+            raise ValueError(f"{what}: {indptr.numel() - 1} rows, but the model has num_users = {self.n['users']}")
+        if int(indptr[-1]) != cols.numel() or (indptr.numel() > 1 and bool((indptr[1:] < indptr[:-1]).any())):
+            raise ValueError(f"{what}: indptr is not a monotone row pointer over {cols.numel()} stored entries")
+        if cols.numel():
+            lo, hi = int(cols.min()), int(cols.max())
+            if lo < 0 or hi >= self.n["items"]:
+                raise IndexError(f"{what}: column index {hi if hi >= self.n['items'] else lo} is out of bounds for "
+                                 f"num_items = {self.n['items']}")
+
     def set_interactions(self, indptr, indices, values):
         """Full user-major confidence matrix (device tensors, CSR as stored).  Builds this rank's
         user-row shard and item-row shard (the transpose is taken here, on the device;
@@ -285,6 +302,7 @@ class AlsEngine:
         indptr = indptr.to(dev, torch.int64)
         cols = indices.to(dev, torch.int64)
         vals = values.to(dev, torch.float32)
+        self._check_csr(indptr, cols, "count_mat")
         counts = indptr[1:] - indptr[:-1]
         rows = torch.repeat_interleave(torch.arange(self.n["users"], device=dev), counts)
         for side, (r_, c_) in (("users", (rows, cols)), ("items", (cols, rows))):
@@ -297,7 +315,7 @@ class AlsEngine:
                 edges = full.indptr[[lo for lo, _ in bounds] + [self.rpr[side]]].tolist()
                 self.csr_chunks[side] = [
                     Csr(self.K, full.indptr[lo: lo + ln + 1] - edges[c], full.indices[edges[c]: edges[c + 1]],
-                        full.values[edges[c]: edges[c + 1]], full.n_cols, self.f)
+                        full.values[edges[c]: edges[c + 1]], full.n_cols, self.f, self.bias)
                     for c, (lo, ln) in enumerate(bounds)]
 
         for side, (r_, c_) in (("users", (rows, cols)), ("items", (cols, rows))):
@@ -351,7 +369,7 @@ class AlsEngine:
             rows, cols, vals = rows[mine], cols[mine], vals[mine]
         local = rows // W
         indptr, idx, v = coo_to_csr(local, self.positions(other, cols), vals, self.rpr[side])
-        return Csr(self.K, indptr, idx, v, W * self.rpr[other], self.f)
+        return Csr(self.K, indptr, idx, v, W * self.rpr[other], self.f, self.bias)
 
     def set_factors(self, side, full):
         """Load a full host/device [n, f] factor matrix (reference layout) into this rank's block."""
@@ -535,22 +553,32 @@ class AlsEngine:
             self._publish(side, c)
 
     def check_numerics(self):
-        """Host sync: raise if a Gramian was not positive definite or a row system was singular."""
-        info, fail = int(self.info[0].item()), int(self.fail[0].item())
+        """Host sync: raise if a Gramian was not positive definite or a row system was singular (the reference's
+        np.linalg.solve raises LinAlgError there).  The two flags are sticky on the device, so one check per iteration
+        sees a failure of either half step; with several ranks they are max-reduced first, so that every rank raises
+        together instead of one leaving the others in the next collective."""
+        flags = torch.stack((self.info[0], self.fail[0])).to(torch.int32)
+        if self.exchange:
+            torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MAX, group=self.group)
+        info, fail = (int(x) for x in flags.cpu())
+        if info or fail:
+            self.info.zero_()
+            self.fail.zero_()
         if info:
             raise _lib.WmfNumericError(f"Gramian + gamma*I is not positive definite (leading minor {info})")
         if fail:
-            self.fail.zero_()
-            raise _lib.WmfNumericError(f"{fail} row systems were singular")
+            raise _lib.WmfNumericError(f"{fail} row systems were singular (largest count over the ranks)")
 
     # ---------------------------------------------------------------- evaluation
     def make_eval_shard(self, indptr, indices, values):
         """User-row shard of a utility matrix for eval_sums (columns are item positions)."""
         dev = self.device
         indptr = indptr.to(dev, torch.int64)
+        cols = indices.to(dev, torch.int64)
+        self._check_csr(indptr, cols, "utility_mat / eval_mat")
         counts = indptr[1:] - indptr[:-1]
         rows = torch.repeat_interleave(torch.arange(self.n["users"], device=dev), counts)
-        return self._shard("users", rows, indices.to(dev, torch.int64), values.to(dev, torch.float32))
+        return self._shard("users", rows, cols, values.to(dev, torch.float32))
 
     def eval_sums(self, shard):
         """(sum of squared errors, sum of absolute errors, count) over the stored non-zero entries

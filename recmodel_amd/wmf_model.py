@@ -42,17 +42,21 @@ class WMF(RecModel):
         self.weighted = weighted
         self.dtype = dtype
         self._engine = None
-        self._dev = None           # (id(users), id(items), users_t, items_t) cache for predict()
+        self._dev = None           # (key, users_t, items_t, f, ld): device copies of the public arrays for predict() / rank()
 
     # ------------------------------------------------------------------ engine plumbing
     def _new_engine(self):
         return AlsEngine(self.num_users, self.num_items, self.dim, self.bias is True, self.gamma)
 
     def _device_factors(self):
-        """Device copies of the public host arrays (re-uploaded when the user swapped them)."""
+        """Device copies of the public host arrays.  The arrays ``train`` leaves behind are read-only (assign a new array
+        to change the factors): their copies are cached by identity.  A writable array -- the constructor's ``items``, or
+        anything the caller assigned -- may have been edited in place since the last call, which the reference would see
+        (it reads the arrays live, wmf_model.py:205-211), so such an array is uploaded again on every call."""
         _lib.require_gpu()
-        key = (id(self.users), id(self.items))
-        if self._dev is None or self._dev[0] != key:
+        frozen = not (self.users.flags.writeable or self.items.flags.writeable)
+        key = (id(self.users), id(self.items), self.users.shape, self.items.shape)
+        if self._dev is None or self._dev[0] != key or not frozen:
             lib = _lib.load()
             f = self.items.shape[1]
             ld = int(lib.wmf_ld_for(f))
@@ -176,13 +180,23 @@ class WMF(RecModel):
         return eng.eval_sums(shard)
 
     def _stale(self):
+        """True when the public arrays are not (or may no longer be) what the engine holds."""
+        if self.users is None or self.users.flags.writeable or self.items.flags.writeable:
+            return True
         return getattr(self, "_synced", None) != (id(self.users), id(self.items))
+
+    def _freeze(self):
+        """The arrays handed out after training mirror device state: in-place edits would silently not reach predict /
+        rank / eval_prec, so they are made read-only (an edit raises; assigning a fresh array works as in the reference)."""
+        self.users.flags.writeable = False
+        self.items.flags.writeable = False
+        self._synced = (id(self.users), id(self.items))
+        self._dev = None
 
     def _pull(self, eng, sides=("users", "items")):
         for s in sides:
             setattr(self, s, eng.get_factors(s).astype(self.dtype, copy=False))
-        self._synced = (id(self.users), id(self.items))
-        self._dev = None
+        self._freeze()
 
     # ------------------------------------------------------------------ a3 / a4: operator seam
     def recompute_factors(self, Y, C, lambda_reg):
@@ -260,7 +274,7 @@ class WMF(RecModel):
                     break
             self._pull(eng)
             self.users, self.items = self.users.astype(np.float64), self.items.astype(np.float64)
-            self._synced = (id(self.users), id(self.items))
+            self._freeze()
             if verbose > 0:
                 print("Training was completed.")
             if verbose > 1:
@@ -309,7 +323,7 @@ class WMF(RecModel):
             # dtype quirk of the reference: its Pool variants (wmf_model.py:242-265) stack float64 row results
             # without the cast back to self.dtype.  Values are the float32 results, widened.
             self.users, self.items = self.users.astype(np.float64), self.items.astype(np.float64)
-            self._synced = (id(self.users), id(self.items))
+            self._freeze()
         if verbose > 0:
             print("Training was completed.")
         if verbose > 1:

@@ -25,12 +25,15 @@ class NumpyKernels:
 
     def factorize(self, G, f, ld, lam, W_white, W_unwhite, info, ws):
         A = G.numpy().reshape(f, f) + lam * np.eye(f)
-        Linv = np.linalg.inv(np.linalg.cholesky(A))
         W_white.numpy()[:] = 0
         W_unwhite.numpy()[:] = 0
+        try:
+            Linv = np.linalg.inv(np.linalg.cholesky(A))
+        except np.linalg.LinAlgError:
+            info.numpy()[0] = 1             # sticky, like the device kernel: only the caller resets it
+            return
         W_white.numpy()[:, :f] = Linv.T
         W_unwhite.numpy()[:, :f] = Linv
-        info.numpy()[0] = 0
 
     def row_transform(self, inp, m, f, ld, W, set_col0_one, out, col0_out):
         x = inp.numpy()[:m, :f].astype(np.float64).copy()
@@ -42,9 +45,9 @@ class NumpyKernels:
         o[:m] = 0
         o[:m, :f] = x @ W.numpy()[:, :f].astype(np.float64)
 
-    def plan_create(self, indptr_host, n, f):
+    def plan_create(self, indptr_host, n, f, bias=False):
         deg = np.diff(indptr_host)
-        stats = np.zeros(8, dtype=np.int64)
+        stats = np.zeros(10, dtype=np.int64)
         stats[0], stats[4] = n, deg.sum()
         return ("plan", n, f), stats
 

@@ -57,7 +57,10 @@ def test_pure_host_entry_points(lib):
     assert [lib.wmf_ld_for(f) for f in (1, 16, 64, 65, 129, 257)] == [4, 16, 64, 68, 132, 260]
     assert lib.wmf_gram_workspace_bytes(64) > 0 and lib.wmf_gram_workspace_bytes(0) == 0
     assert lib.wmf_eval_workspace_bytes() > 0
-    assert lib.wmf_profile_slot_name(4).decode().startswith("solve_low_kernel")
+    assert lib.wmf_profile_reset() == 0 and lib.wmf_profile_collect() == 0       # nothing recorded: an empty table
+    assert lib.wmf_profile_entry(0, None, 0, None, None, None, None, None) == -1  # WMF_EINVAL, no entry 0
+    assert lib.wmf_debug_set_flags(2) == -1                                      # ablation switches: -DWMF_LAB builds only
+    assert lib.wmf_debug_set_flags(0) == 0
 
 
 def test_argument_validation_without_gpu(lib):
@@ -75,7 +78,7 @@ def test_argument_validation_without_gpu(lib):
     bad_ptr = np.array([0, 2, 1], dtype=np.int64)   # not monotone
     plan = ctypes.c_void_p()
     with pytest.raises(ValueError):
-        _lib.check(lib.wmf_plan_create(bad_ptr.ctypes.data_as(ctypes.c_void_p), 2, 16, ctypes.byref(plan)))
+        _lib.check(lib.wmf_plan_create(bad_ptr.ctypes.data_as(ctypes.c_void_p), 2, 16, 0, ctypes.byref(plan)))
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -162,3 +162,36 @@ def test_single_rank_engine_with_stand_in_matches_oracle():
     eng3.set_factors("items", orc.init_items(n_items, dim))
     eng3.half_step("users")
     np.testing.assert_array_equal(eng3.get_factors("users"), eng.get_factors("users"))
+
+
+def _worker_singular(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_kernels import NumpyKernels
+        from recmodel_amd import _lib
+        from recmodel_amd.engine import AlsEngine
+        eng = AlsEngine(8, 6, 3, False, 0.1, device="cpu", kernels=NumpyKernels(), chunks=1)
+        if rank == 1:
+            eng.fail[0] = 3                      # a singular row system seen by ONE rank only
+        raised = False
+        try:
+            eng.check_numerics()
+        except _lib.WmfNumericError:
+            raised = True
+        # a collective right after the check: with a per-rank decision rank 1 would have left and rank 0 would hang here
+        t = torch.tensor([1.0 if raised else 0.0])
+        dist.all_reduce(t)
+        if rank == 0:
+            np.save(out_path, np.array([float(t), float(eng.fail[0])]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_numeric_failure_on_one_rank_raises_on_all(tmp_path):
+    out = str(tmp_path / "flags.npy")
+    mp.spawn(_worker_singular, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    assert got[0] == 2.0 and got[1] == 0.0       # both ranks raised; the flag was reset

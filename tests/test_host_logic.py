@@ -141,3 +141,69 @@ def test_reduce_mode_is_chosen_from_the_bytes_per_link(monkeypatch):
         assert e.reduce == {"users": False, "items": want}, (world, e.reduce)
         assert len(e.chunk_bounds["users"]) == (1 if want else 4)
         assert len(e.chunk_bounds["items"]) == (3 if want else 1)
+
+
+def _tiny_engine(n_users=12, n_items=7, dim=3, gamma=0.1):
+    from fake_kernels import NumpyKernels
+    from recmodel_amd import engine
+    return engine.AlsEngine(n_users, n_items, dim, False, gamma, device="cpu", kernels=NumpyKernels())
+
+
+def test_column_ids_outside_the_catalogue_raise_like_the_reference():
+    """The reference indexes the fixed factors with the stored column ids (wmf_model.py:233) and raises IndexError
+    for an id >= num_items; the engine turns the ids into gather positions of device kernels, so it has to refuse
+    them when the matrix is handed over (count_mat, eval_mat and utility_mat alike)."""
+    eng = _tiny_engine()
+    indptr = torch.arange(0, 13, dtype=torch.int64)
+    vals = torch.ones(12)
+    ok = torch.arange(12) % 7
+    eng.set_interactions(indptr, ok, vals)                                   # fits
+    eng.make_eval_shard(indptr, ok, vals)
+    wide = ok.clone()
+    wide[5] = 7                                                              # one id == num_items
+    with pytest.raises(IndexError):
+        eng.set_interactions(indptr, wide, vals)
+    with pytest.raises(IndexError):
+        eng.make_eval_shard(indptr, wide, vals)
+    with pytest.raises(IndexError):
+        eng.set_interactions(indptr, -wide, vals)                            # negative ids
+    with pytest.raises(ValueError):
+        eng.set_interactions(indptr[:-1], ok[:-1], vals[:-1])                # 11 rows for 12 users
+    with pytest.raises(IndexError):                                          # the building block refuses too
+        coo_to_csr(torch.tensor([0, 4]), torch.tensor([0, 0]), torch.ones(2), 4)
+
+
+def test_failed_gramian_factorisation_is_sticky():
+    """gamma = 0 and fewer items than factors: Gram(items) is singular, the users half step fails.  The next Gramian
+    (of all-zero users, plus gamma I = 0) fails too in this case, but even a later success must not clear the flag:
+    check_numerics() after both half steps has to raise, as the reference's np.linalg.solve does."""
+    from recmodel_amd import _lib
+    eng = _tiny_engine(n_users=6, n_items=2, dim=3, gamma=0.0)
+    indptr = torch.arange(0, 7, dtype=torch.int64)
+    eng.set_interactions(indptr, torch.arange(6) % 2, torch.ones(6))
+    eng.set_factors("items", np.ones((2, 3), dtype=np.float32))
+    eng.half_step("users")
+    assert int(eng.info[0]) == 1
+    eng.gamma = 1.0                                                          # the items half step factorises fine ...
+    eng.half_step("items")
+    assert int(eng.info[0]) == 1                                             # ... and does not hide the failure
+    with pytest.raises(_lib.WmfNumericError):
+        eng.check_numerics()
+    assert int(eng.info[0]) == 0                                             # reset by the check that reported it
+    eng.check_numerics()
+
+
+def test_public_factor_arrays_are_read_only_after_training_and_writable_ones_are_never_cached():
+    """predict / rank / eval_prec score device copies of model.users / model.items.  What train() leaves behind is
+    read-only (an in-place edit raises instead of silently not reaching the device); arrays the caller assigns stay
+    writable and are uploaded on every call (wmf_model.WMF._device_factors)."""
+    m = WMF(num_items=5, num_users=4, dim=2, gamma=0.1, weighted=True)
+    m.users = np.zeros((4, 2), dtype=np.float32)
+    assert m._stale()                                     # writable arrays: never trusted to match the engine
+    m._freeze()
+    assert not m._stale()
+    with pytest.raises(ValueError):
+        m.items[0, 0] = 1.0
+    m.items = m.items.copy()                              # assigning a fresh array works as in the reference
+    m.items[0, 0] = 1.0
+    assert m._stale()

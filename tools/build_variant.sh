@@ -9,6 +9,7 @@ c=$root/recmodel_amd/csrc
 mkdir -p $root/build/variants
 make -s -C $c
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wall -Wno-unused-function $extra -c $c/$src -o $root/build/variants/$name.o
+if [ "$src" = "wmf_directl.hip" ]; then python3 $root/tools/check_inflight_regs.py $c/$src $extra; fi
 objs=""
 for o in $c/*.o; do
   [ "$(basename $o)" = "${src%.hip}.o" ] && continue

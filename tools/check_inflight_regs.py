@@ -2,13 +2,16 @@
 some time after the instruction issues; hipcc believes they are written at once.  Between each such read and the
 inline-asm `s_waitcnt lgkmcnt(0)` that retires it nothing may touch those registers (a copy the register allocator
 inserts there would copy stale data).  Parses the gfx950 assembly of the file and reports violations.
-Usage: python tools/check_inflight_regs.py [path/to/wmf_directl.hip]"""
+Usage: python tools/check_inflight_regs.py [path/to/wmf_directl.hip] [extra compiler flags ...]
+Run by recmodel_amd/csrc/Makefile on the flags of the build itself (a violation fails the build); the scan follows the
+text order of the assembly, not its control flow, which is enough for the straight-line read / wait pairs of this file."""
 import re, subprocess, sys, os, tempfile
 
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), "..", "recmodel_amd", "csrc", "wmf_directl.hip")
-out = os.path.join(tempfile.gettempdir(), "wmf_directl_check.s")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-S", "--cuda-device-only", "-o", out, src],
-               check=True, stderr=subprocess.DEVNULL)
+extra = sys.argv[2:]
+out = os.path.join(tempfile.mkdtemp(prefix="wmf_inflight_"), "wmf_directl_check.s")
+subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", *extra, "-S",
+                "--cuda-device-only", "-o", out, src], check=True, stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
 reg_re = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 

@@ -38,7 +38,6 @@ for fl in flags:
                                       _ptr(c.indices), _ptr(c.values), c.n_rows, eng.f, eng.ld, _ptr(eng.g[side]), _ptr(eng.fail), _stream()))
     torch.cuda.synchronize()
     lib.wmf_profile_enable(0)
-    ms = np.zeros(_lib.WMF_PROF_SLOTS); ln = np.zeros(_lib.WMF_PROF_SLOTS, dtype=np.int64)
-    lib.wmf_profile_read(ms.ctypes.data_as(ctypes.c_void_p), ln.ctypes.data_as(ctypes.c_void_p))
-    print(f"flags={fl}: " + ", ".join(f"{lib.wmf_profile_slot_name(s).decode()}={ms[s]/reps:.3f}ms/{ln[s]//reps}" for s in range(_lib.WMF_PROF_SLOTS) if ln[s]))
+    print(f"flags={fl}: " + ", ".join(f"{nm}={ms / reps:.3f}ms/{n // reps}" for nm, _, ms, n, _, _ in _lib.profile_table(lib)))
+    lib.wmf_profile_reset()
 lib.wmf_debug_set_flags(0)
