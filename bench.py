@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
-"""WMF/ALS throughput on MI355X: one "step" = one ALS iteration (users half step + items half
-step, each with its Gramian, factorisation, whitening, row solve and -- on more than one GPU --
-the Gramian all-reduce and the all-gather of the whitened block) over a synthetic confidence
-matrix that is already resident in HBM.
+"""WMF/ALS throughput on MI355X.  One "step" = one ALS iteration (users half step + items half step, each with its
+Gramian, factorisation, whitening, row solve and -- on more than one GPU -- the Gramian all-reduce and the exchange of
+the freshly solved block) over a synthetic confidence matrix that is already resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|tiny] [--zipf A]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3] [--also cfg2|none] [--scaling strong|weak] [--zipf A]
 
-For N > 1 the driver launches one rank per GPU through torch.distributed.run; ranks talk RCCL.
-Scaling is weak: each GPU brings its own ``n_users`` users (the item catalogue is shared), so the
-stored entries per GPU stay fixed.  Rank 0 prints ONE JSON line.
+Default workload = BASELINE.json configs[2] (the configuration the north-star target is quoted on): k = 128 with
+user / item biases, 10 M x 1 M, ~100 M stored entries.  configs[1] (cfg2: k = 64, 1 M x 100 K, 20 M entries) is timed
+in the same process afterwards and reported under "also".  For N > 1 the driver launches one rank per GPU through
+torch.distributed.run (RCCL); the default there is STRONG scaling -- BASELINE.json configs[3]: the same 10 M x 1 M
+matrix at k = 128, users and items dealt over the N GPUs -- with the bias-free variant (cfg4) under "also".
+Rank 0 prints ONE JSON line.
+
+Roofline bookkeeping.  Every kernel launch is timed with HIP events on its own stream
+(wmf_profile_* in the C ABI), keyed by the symbol rocprofv3 prints and by the half step it ran in.  Algorithmic bytes
+of a row kernel = sum over ITS rows of (4f + 8) x entries + (4f + 4): what the reference's Y[idx] gather, the CSR
+entry and the written row amount to, whatever the kernel really moves.  "traffic" is NOT measured in this run: it is
+the HBM byte count of the same kernel in the newest committed rocprofv3 --pmc profile of this workload
+(profiles/rNN_<config>_traffic.json, named in "traffic_source").
 """
 import argparse
-import ctypes
+import glob
 import json
 import os
 import sys
@@ -26,17 +35,22 @@ sys.path.insert(0, ROOT)
 from recmodel_amd import _lib, synth  # noqa: E402
 from recmodel_amd.engine import AlsEngine  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
-F32_MFMA_PEAK_TF = 157.3  # dense f32-input MFMA peak
-SOLVE_BINS = {4: 0, 5: 1, 11: 2, 6: 3}   # profile slot -> plan bin whose rows that kernel processes
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+F32_MFMA_PEAK_TF = 157.3    # dense f32-input MFMA peak: what an exact-f32 Gramian is priced against
+SIDES = ("users", "items")
+SEEDS = {"cfg1": 1994, "cfg2": 1995, "cfg3": 1996, "cfg4": 1996, "cfg3m": 1996, "cfg5s": 1998, "tiny": 2002}   # 1993 + config index
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="cfg2", choices=sorted(synth.CONFIGS))
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg3", choices=sorted(synth.CONFIGS))
+    ap.add_argument("--also", default="auto", help="second workload reported under 'also' (auto: cfg2 on one GPU, the "
+                    "bias-free cfg4 on several; none: skip)")
+    ap.add_argument("--scaling", default="auto", choices=("auto", "strong", "weak"),
+                    help="N > 1: strong = the same matrix dealt over the ranks (default), weak = N times the users")
     ap.add_argument("--zipf", type=float, default=0.0, help="item popularity exponent (0 = uniform)")
     ap.add_argument("--chunks", type=int, default=0,
                     help="solve each side in this many chunks (0 = engine default: 1 on one GPU, 4 on several, where "
@@ -82,7 +96,7 @@ def cpu_baseline(cfg_name, user_rows, item_rows, users_f, k, bias, gamma, n_item
     out = {"value": rows / (t_u + t_i), "unit": "row-updates/s", "cores": 1, "kind": "port",
            "sample": f"{cfg_name}: first {C.shape[0]} user rows ({C.nnz} nnz, {t_u:.1f}s) + first {CT.shape[0]} item rows "
                      f"({CT.nnz} nnz, {t_i:.1f}s) of the same matrix, NumPy per-row loop, 1 BLAS thread",
-           "host_cpus": os.cpu_count()}
+           "nnz_per_s": (C.nnz + CT.nnz) / (t_u + t_i), "host_cpus": os.cpu_count()}
     # the "fair" CPU figure of SURVEY.md 8(d): the oracle's C restatement (float64, own LU) with OpenMP on every
     # host core, same sample
     try:
@@ -117,26 +131,218 @@ def host_boundary(user_rows, k, bias, gamma, n_items):
             "pcie_megabytes": mb, "note": "one user half step through wmf_recompute_factors_host, PCIe-inclusive"}
 
 
-def measured_traffic(config, slot, f, ld):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC profile of this
-    workload (profiles/rNN_<config>_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
-    this same command, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent."""
-    import glob
-    nfb, nch = (f + 15) // 16, (ld + 15) // 16
-    nfb_heavy = f // 16 if (f > 16 and f % 16 == 1 and (f // 16) % 4 != 3) else nfb     # border variant of the heavy-row kernel
-    heavy = f"solve_directw_kernel<{nfb_heavy}, 0"
-    if (f, ld) in ((128, 128), (129, 132)):                          # k = 128: the LDS-DMA ring kernel (wmf_directl.hip)
-        heavy = "solve_directl_kernel<8, " + ("true" if f == 129 else "false")
-    key = {0: f"gram_kernel<{nfb}, 1>", 3: f"transform_kernel<{nfb}, true", 4: f"solve_low_kernel<{nch}, 1,",
-           5: f"solve_low_kernel<{nch}, 2", 11: heavy}.get(slot)
+# --------------------------------------------------------------------------------------- roofline bookkeeping
+def kernel_work(name, csr, eng, side):
+    """(bound, algorithmic units per launch) of kernel ``name`` launched in the half step that updates ``side``;
+    None for kernels without a byte / flop model here (factorisation, reductions, fallbacks)."""
+    f = eng.f
+    row_b, ent_b = 4 * f + 4, 4 * f + 8
+    rows, nnz = csr.bin_rows, csr.bin_nnz
+    fixed = "items" if side == "users" else "users"
+    if name.startswith("solve_pair_kernel"):
+        return "hbm", csr.nnz8 * ent_b + csr.rows8 * row_b
+    if name.startswith("solve_low_kernel") and ", 1," in name:
+        return "hbm", (nnz[0] - csr.nnz8) * ent_b + (rows[0] - csr.rows8) * row_b
+    if name.startswith("solve_low_kernel"):
+        return "hbm", nnz[1] * ent_b + rows[1] * row_b
+    if name.startswith("solve_directl_kernel") or name.startswith("solve_directw_kernel") and ", 0," in name:
+        return "hbm", (nnz[2] - csr.nnz_split) * ent_b + (rows[2] - csr.rows_split) * row_b
+    if name.startswith("solve_directw_kernel") and ", 1," in name:          # segments of the split rows: the gathers
+        return "hbm", csr.nnz_split * ent_b
+    if name.startswith("solve_rowsplit_kernel") or name.startswith("solve_wide_kernel"):
+        return "hbm", nnz[3] * ent_b + rows[3] * row_b
+    if name.startswith("gram") and "reduce" not in name:
+        return "mfma", 2.0 * f * f * eng.n_local[fixed]
+    return None
+
+
+def transform_work(eng, rows):
+    return "hbm", 8.0 * eng.f * rows                                         # one row read, one row written
+
+
+def traffic_table(config):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config}_traffic.json")))
-    if not key or not files:
+    if not files:
+        return None, None
+    return json.load(open(files[-1])).get("kernels", {}), os.path.relpath(files[-1], ROOT)
+
+
+def traffic_of(table, name, side, both_sides):
+    """HBM bytes per launch of ``name`` from the committed PMC profile (2 x FETCH_SIZE + WRITE_SIZE, the gfx950
+    correction of MI355X_MICROARCH.md); per side when the profile kept the dispatches of the two half steps apart."""
+    if not table:
         return None
-    table = json.load(open(files[-1])).get("kernels", {})
-    k = next((v for name, v in table.items() if name.startswith(key)), None)       # template arguments may follow
-    if not k or k.get("FETCH_SIZE_KB_mean") is None:
+    k = next((v for n, v in table.items() if n.startswith(name)), None)
+    if not k:
         return None
-    return (2.0 * k["FETCH_SIZE_KB_mean"] + k.get("WRITE_SIZE_KB_mean", 0.0)) * 1024.0
+    if both_sides and k.get("hbm_bytes_by_side"):
+        return k["hbm_bytes_by_side"].get(side)
+    return k.get("hbm_bytes_mean_corrected")
+
+
+def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu):
+    n_users_1, n_items, dbar, k, bias = synth.CONFIGS[cfg_name]
+    n_users = n_users_1 * world if scaling == "weak" else n_users_1
+    gamma = 0.1
+    seed = SEEDS[cfg_name]
+
+    # ---- synthetic workload, generated on the GPU (identical on every rank) -----------------
+    t0 = time.perf_counter()
+    blocks = world if scaling == "weak" else 1
+    parts = [synth.make_counts(n_users_1, n_items, dbar, seed, device=dev, zipf_a=args.zipf, first_user=b * n_users_1)
+             for b in range(blocks)]
+    ptrs, offset = [parts[0][0][:1]], 0
+    for ip_b, _, _ in parts:
+        ptrs.append(ip_b[1:] + offset)
+        offset += int(ip_b[-1])
+    indptr = torch.cat(ptrs)
+    indices = torch.cat([p[1] for p in parts])
+    counts = torch.cat([p[2] for p in parts])
+    del parts, ptrs
+    nnz = int(indices.numel())
+    eng = AlsEngine(n_users, n_items, k, bias, gamma, device=dev, chunks=args.chunks or None)
+    values = counts.clone()
+    eng.K.confidence_transform(values, 10.0, 1.0, 0)
+    eng.set_interactions(indptr, indices, values)
+    from recmodel_amd import WMF                    # the package's own constructor draws the initial item factors
+    eng.set_factors("items", WMF(num_items=n_items, num_users=1, dim=k, gamma=gamma, weighted=True, bias=bias).items)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        lib.wmf_profile_set_tag(0)
+        eng.half_step("users")
+        lib.wmf_profile_set_tag(1)
+        eng.half_step("items")
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.check_numerics()
+    lib.wmf_profile_reset()
+    lib.wmf_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.wmf_profile_enable(0)
+    eng.check_numerics()
+    table = _lib.profile_table(lib)
+    lib.wmf_profile_reset()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- eval pass (not part of the timed step; reported separately) ------------------------
+    shard = eng.make_eval_shard(indptr, indices, counts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sq, ab, cnt = eng.eval_sums(shard)
+    torch.cuda.synchronize()
+    t_eval = time.perf_counter() - t0
+
+    # ---- per-kernel table and rooflines (this rank's launches) --------------------------------
+    f = eng.f
+    traffic, traffic_src = traffic_table(cfg_name)
+    names_both = {n for n, t, *_ in table if t == 0} & {n for n, t, *_ in table if t == 1}
+    kernels, solve_ms = [], {s: 0.0 for s in SIDES}
+    for name, tag, ms, launches, lo, hi in sorted(table, key=lambda e: -e[2]):
+        side = SIDES[tag] if tag in (0, 1) else "?"
+        entry = {"kernel": name, "half_step": side, "launches": int(launches), "avg_ms": ms / launches, "min_ms": lo,
+                 "max_ms": hi, "total_ms": ms}
+        work = None
+        if side in SIDES:
+            if name.startswith("transform"):
+                # two launches per half step: the whitening of the fixed side, then the un-whitening of the solved rows
+                fixed = "items" if side == "users" else "users"
+                work = transform_work(eng, (eng.world * eng.rpr[fixed] + eng.n_local[side]) / 2.0)
+            else:
+                work = kernel_work(name, eng.csr[side], eng, side)
+            if name.startswith(("solve_", "bias_adjust")):
+                solve_ms[side] += ms / args.steps
+        if work and work[1] > 0:
+            bound, units = work
+            peak, unit, scale = (HBM_PEAK_GBS, "GB/s", 1e9) if bound == "hbm" else (F32_MFMA_PEAK_TF, "TFLOP/s", 1e12)
+            ach = units / (ms / launches / 1e3) / scale
+            entry.update({"bound": bound, "algorithmic_units_per_launch": float(units), "achieved": ach, "peak": peak,
+                          "unit": unit, "frac": ach / peak,
+                          "traffic": traffic_of(traffic, name, side, name in names_both)})
+        kernels.append(entry)
+    cand = [e for e in kernels if "frac" in e]
+    roofline = None
+    if cand:
+        dom = max(cand, key=lambda e: e["total_ms"])
+        roofline = {"kernel": dom["kernel"], "half_step": dom["half_step"], "bound": dom["bound"], "achieved": dom["achieved"],
+                    "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": dom["traffic"],
+                    "traffic_source": (f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this workload, "
+                                       "2 x FETCH + WRITE; not measured in this run") if dom["traffic"] is not None else None,
+                    "algorithmic_units_per_launch": dom["algorithmic_units_per_launch"], "avg_launch_ms": dom["avg_ms"],
+                    "launches": dom["launches"], "share_of_step": dom["total_ms"] / (elapsed * 1e3)}
+    # the north star's named target: the per-user solve (every row kernel of the users half step together)
+    half = {}
+    for s in SIDES:
+        c = eng.csr[s]
+        b = c.nnz * (4 * f + 8) + eng.n_local[s] * (4 * f + 4)
+        half[s] = {"algorithmic_bytes": float(b), "solve_kernels_ms": solve_ms[s],
+                   "achieved": b / (solve_ms[s] / 1e3) / 1e9 if solve_ms[s] > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": b / (solve_ms[s] / 1e3) / 1e9 / HBM_PEAK_GBS if solve_ms[s] > 0 else None, "bound": "hbm",
+                   "kernels": sorted({e["kernel"] for e in kernels if e["half_step"] == s and e["kernel"].startswith(("solve_", "bias_adjust"))})}
+    epoch_bytes = sum(eng.algorithmic_bytes_half(s) for s in SIDES)
+    if world > 1:
+        eb = torch.tensor([epoch_bytes], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(eb)
+        epoch_bytes = float(eb.item())
+
+    out = {
+        "value": (n_users + n_items) * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+        "config": {"workload": f"{cfg_name}: WMF k={k}{'+bias' if bias else ''}, {n_users}x{n_items} CSR, "
+                               f"{nnz} nnz, alpha-log confidence, gamma={gamma}, zipf_a={args.zipf}",
+                   "n_users": n_users, "n_items": n_items, "nnz": nnz, "k": k, "bias": bias,
+                   "sharding": f"users+items round-robin over {world} GPU(s); exchange users: "
+                               f"{'reduce-scatter of partial systems' if eng.reduce['users'] else 'all-gather'} in "
+                               f"{len(eng.chunk_bounds['users'])} chunk(s), items: "
+                               f"{'reduce-scatter of partial systems' if eng.reduce['items'] else 'all-gather'} in "
+                               f"{len(eng.chunk_bounds['items'])} chunk(s); accumulation pipelined over arriving chunks: "
+                               f"{[s_ for s_ in SIDES if eng.pipe[s_]] or 'no'}"},
+        "nnz_per_s": 2.0 * nnz * args.steps / elapsed,
+        "epoch_algorithmic_GBps": epoch_bytes * args.steps / elapsed / 1e9,
+        "epoch_hbm_frac": epoch_bytes * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),
+        "roofline": roofline, "roofline_user_solve": half["users"], "roofline_item_solve": half["items"],
+        "kernels": kernels,
+        "eval": {"ms": t_eval * 1e3, "mse": sq / cnt if cnt else None},
+        "setup_s": t_setup,
+        "row_bins": {s: {"rows": eng.csr[s].bin_rows.tolist(), "nnz": eng.csr[s].bin_nnz.tolist(),
+                         "rows_le8": eng.csr[s].rows8, "rows_split": eng.csr[s].rows_split} for s in SIDES},
+    }
+    if with_cpu:
+        su = args.cpu_users or {64: 300_000, 128: 60_000, 16: 943, 256: 12_000}.get(k, 20_000)
+        su = min(su, n_users_1)
+        si = max(1, min(n_items, su * n_items // n_users_1))
+        ip = indptr[: su + 1].cpu().numpy()
+        user_rows = synth.to_scipy(indptr[: su + 1], indices[: ip[-1]], counts[: ip[-1]], (su, n_items))
+        ci = eng.csr["items"]                                    # item-major confidence matrix (world == 1: positions = ids)
+        ipi = ci.indptr[: si + 1].cpu().numpy()
+        item_rows = synth.to_scipy(ci.indptr[: si + 1], ci.indices[: ipi[-1]].to(torch.int64), ci.values[: ipi[-1]],
+                                   (si, n_users))
+        if n_users <= 2_000_000:
+            users_f = eng.get_factors("users")
+        else:                                                    # timing does not depend on the values
+            users_f = np.random.default_rng(0).random((n_users, eng.f), dtype=np.float32)
+        out["cpu_baseline"] = cpu_baseline(cfg_name, user_rows, item_rows, users_f, k, bias, gamma, n_items)
+        out["host_boundary"] = host_boundary(user_rows, k, bias, gamma, n_items)
+        del users_f
+    del eng, indptr, indices, counts, values, shard
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -172,155 +378,35 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     lib = _lib.load()
 
-    n_users_1, n_items, dbar, k, bias = synth.CONFIGS[args.config]
-    n_users = n_users_1 * world                     # weak scaling over users
-    gamma = 0.1
-    seed = 1993 + {"cfg1": 1, "cfg2": 2, "cfg3": 3, "cfg4": 3, "cfg5s": 5, "tiny": 9}[args.config]
-
-    # ---- synthetic workload, generated on the GPU (identical on every rank) -----------------
-    t0 = time.perf_counter()
-    parts = [synth.make_counts(n_users_1, n_items, dbar, seed, device=dev, zipf_a=args.zipf, first_user=b * n_users_1)
-             for b in range(world)]
-    ptrs, offset = [parts[0][0][:1]], 0
-    for ip_b, _, _ in parts:
-        ptrs.append(ip_b[1:] + offset)
-        offset += int(ip_b[-1])
-    indptr = torch.cat(ptrs)
-    indices = torch.cat([p[1] for p in parts])
-    counts = torch.cat([p[2] for p in parts])
-    del parts, ptrs
-    nnz = int(indices.numel())
-    eng = AlsEngine(n_users, n_items, k, bias, gamma, device=dev, chunks=args.chunks or None)
-    values = counts.clone()
-    eng.K.confidence_transform(values, 10.0, 1.0, 0)
-    eng.set_interactions(indptr, indices, values)
-    from recmodel_amd import WMF                    # the package's own constructor draws the initial item factors
-    eng.set_factors("items", WMF(num_items=n_items, num_users=1, dim=k, gamma=gamma, weighted=True, bias=bias).items)
-    torch.cuda.synchronize()
-    t_setup = time.perf_counter() - t0
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    def step():
-        eng.half_step("users")
-        eng.half_step("items")
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    eng.check_numerics()
-    lib.wmf_profile_enable(1)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    lib.wmf_profile_enable(0)
-    eng.check_numerics()
-    ms = np.zeros(_lib.WMF_PROF_SLOTS)
-    launches = np.zeros(_lib.WMF_PROF_SLOTS, dtype=np.int64)
-    lib.wmf_profile_read(ms.ctypes.data_as(ctypes.c_void_p), launches.ctypes.data_as(ctypes.c_void_p))
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    # ---- eval pass (not part of the timed step; reported separately) ------------------------
-    shard = eng.make_eval_shard(indptr, indices, counts)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sq, ab, cnt = eng.eval_sums(shard)
-    torch.cuda.synchronize()
-    t_eval = time.perf_counter() - t0
-
-    # ---- roofline of the dominant kernel (largest total time inside the timed region) ---------
-    f = eng.f
-    kernels = {}
-    for slot in range(_lib.WMF_PROF_SLOTS):
-        if launches[slot]:
-            kernels[lib.wmf_profile_slot_name(slot).decode()] = {
-                "launches": int(launches[slot]), "avg_ms": ms[slot] / launches[slot], "total_ms": float(ms[slot])}
-    n_loc = eng.n_local
-    work = {}          # slot -> (bound, algorithmic units per STEP on this rank)
-    for slot, b in SOLVE_BINS.items():
-        tot = 0
-        for side in ("users", "items"):
-            c = eng.csr[side]
-            rows_b, nnz_b = int(c.bin_rows[b]), int(c.bin_nnz[b])
-            tot += nnz_b * (4 * f + 8) + rows_b * (4 * f + 4)      # gathered + written bytes
-        work[slot] = ("hbm", float(tot))
-    rows_all = n_loc["users"] + n_loc["items"]
-    work[0] = ("mfma", 2.0 * f * f * rows_all)                     # Gramian: 2 m f^2 flops per side
-    work[3] = ("mfma", 2.0 * f * f * 2 * rows_all)                 # whiten + unwhiten GEMMs
-    cand = [s_ for s_ in work if launches[s_] and work[s_][1] > 0]
-    roofline = None
-    if cand:
-        dom = max(cand, key=lambda s_: ms[s_])
-        bound, units_per_step = work[dom]
-        per_launch = units_per_step * args.steps / launches[dom]
-        avg_s = ms[dom] / launches[dom] / 1e3
-        peak, unit, scale = (HBM_PEAK_GBS, "GB/s", 1e9) if bound == "hbm" else (F32_MFMA_PEAK_TF, "TFLOP/s", 1e12)
-        traffic = measured_traffic(args.config, dom, f, eng.ld)
-        roofline = {"kernel": lib.wmf_profile_slot_name(dom).decode(), "bound": bound,
-                    "achieved": per_launch / avg_s / scale, "peak": peak, "unit": unit,
-                    "frac": per_launch / avg_s / scale / peak, "traffic": traffic,
-                    "algorithmic_units_per_launch": per_launch, "avg_launch_ms": avg_s * 1e3,
-                    "share_of_step": float(ms[dom] / (elapsed * 1e3))}
-    epoch_bytes = sum(eng.algorithmic_bytes_half(s) for s in ("users", "items"))
-    if world > 1:
-        eb = torch.tensor([epoch_bytes], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(eb)
-        epoch_bytes = float(eb.item())
+    scaling = args.scaling if args.scaling != "auto" else "strong"
+    if world == 1:
+        scaling = "weak"                       # one GPU: the per-GPU work is the whole workload either way
+    main_res = run_workload(args.config, args, world, rank, dev, lib, scaling,
+                            with_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+    also_name = args.also
+    if also_name == "auto":
+        also_name = {"cfg3": "cfg2" if world == 1 else "cfg4"}.get(args.config, "none")
+    also = None
+    if also_name != "none" and also_name in synth.CONFIGS:
+        r2 = run_workload(also_name, args, world, rank, dev, lib, scaling,
+                          with_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+        also = {also_name: {"metric": "ALS user+item row-updates/sec", "unit": "row-updates/s", **r2}}
 
     out = {
-        "metric": "ALS user+item row-updates/sec", "value": (n_users + n_items) * args.steps / elapsed,
+        "metric": "ALS user+item row-updates/sec", "value": main_res.pop("value"),
         "unit": "row-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": main_res.pop("ms_per_step"), "higher_is_better": True,
+        "scaling": "weak" if world == 1 else scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "precision_note": "float32 storage, float32 accumulation everywhere; Gramian fp64 across waves; where a kernel is "
                           "MFMA-bound its products are three-way bf16 splits of the float32 operands (six bf16 MFMAs per tile, "
                           "every product exact, result within 1.4x of the f32-MFMA error: DESIGN.md section 5); parity tolerance "
                           "unchanged (tests/test_gpu_parity.py)",
-        "config": {"workload": f"{args.config}: WMF k={k}{'+bias' if bias else ''}, {n_users}x{n_items} CSR, "
-                               f"{nnz} nnz, alpha-log confidence, gamma={gamma}, zipf_a={args.zipf}",
-                   "n_users": n_users, "n_items": n_items, "nnz": nnz, "k": k, "bias": bias,
-                   "sharding": f"users+items round-robin over {world} GPU(s); exchange users: "
-                               f"{'reduce-scatter of partial systems' if eng.reduce['users'] else 'all-gather'} in "
-                               f"{len(eng.chunk_bounds['users'])} chunk(s), items: "
-                               f"{'reduce-scatter of partial systems' if eng.reduce['items'] else 'all-gather'} in "
-                               f"{len(eng.chunk_bounds['items'])} chunk(s); accumulation pipelined over arriving chunks: "
-                               f"{[s_ for s_ in ('users', 'items') if eng.pipe[s_]] or 'no'}"},
-        "nnz_per_s": 2.0 * nnz * args.steps / elapsed,
-        "epoch_algorithmic_GBps": epoch_bytes * args.steps / elapsed / 1e9,
-        "epoch_hbm_frac": epoch_bytes * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),
-        "roofline": roofline, "kernels": kernels,
-        "eval": {"ms": t_eval * 1e3, "mse": sq / cnt if cnt else None},
-        "setup_s": t_setup,
-        "row_bins": {s: {"rows": eng.csr[s].bin_rows.tolist(), "nnz": eng.csr[s].bin_nnz.tolist()} for s in ("users", "items")},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        su = args.cpu_users or {64: 300_000, 128: 60_000, 16: 943, 256: 12_000}.get(k, 20_000)
-        su = min(su, n_users_1)
-        si = max(1, min(n_items, su * n_items // n_users_1))
-        ip = indptr[: su + 1].cpu().numpy()
-        user_rows = synth.to_scipy(indptr[: su + 1], indices[: ip[-1]], counts[: ip[-1]], (su, n_items))
-        ci = eng.csr["items"]                                    # item-major confidence matrix (world == 1: positions = ids)
-        ipi = ci.indptr[: si + 1].cpu().numpy()
-        item_rows = synth.to_scipy(ci.indptr[: si + 1], ci.indices[: ipi[-1]].to(torch.int64), ci.values[: ipi[-1]],
-                                   (si, n_users))
-        if n_users <= 2_000_000:
-            users_f = eng.get_factors("users")
-        else:                                                    # timing does not depend on the values
-            users_f = np.random.default_rng(0).random((n_users, eng.f), dtype=np.float32)
-        out["cpu_baseline"] = cpu_baseline(args.config, user_rows, item_rows, users_f, k, bias, gamma, n_items)
-        out["host_boundary"] = host_boundary(user_rows, k, bias, gamma, n_items)
-    elif rank == 0:
-        out["cpu_baseline"] = None
+    cpu = main_res.pop("cpu_baseline", None)
+    out.update(main_res)
+    out["cpu_baseline"] = cpu
+    out["also"] = also
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -96,10 +96,11 @@ int wmf_row_transform(const float* in, int64_t m, int f, int ld, const float* W,
  * be solved with a bias vector. */
 int  wmf_plan_create(const int64_t* indptr_host, int64_t n, int f, int bias, wmf_plan** out);
 void wmf_plan_destroy(wmf_plan* p);
-/* Rows and stored entries the plan routes to each kernel family: out10[b] = rows, out10[4+b] =
- * stored entries, for b = 0: <=16 entries, 1: 17..32, 2: MFMA Gramian path, 3: general LU path;
- * out10[8], out10[9] = rows and entries of bin 0 with at most 8 entries (two rows share a wave). */
-int  wmf_plan_stats(const wmf_plan* p, int64_t* out10);
+/* Rows and stored entries the plan routes to each kernel family: out12[b] = rows, out12[4+b] =
+ * stored entries, for b = 0: <=16 entries, 1: 17..32, 2: one wave per row (f <= 144), 3: four waves per row (f > 144);
+ * out12[8], out12[9] = rows and entries of bin 0 with at most 8 entries (two rows share a wave);
+ * out12[10], out12[11] = rows and entries of bin 2 with more than 4096 entries (split over several waves). */
+int  wmf_plan_stats(const wmf_plan* p, int64_t* out12);
 
 /* The per-row normal-equation solve in whitened coordinates, for every row of the CSR:
  *   g_u = (I + V_u^T D_u V_u)^-1 V_u^T (w_u + 1),   V_u = V[idx_u], D_u = diag(w_u)

@@ -236,6 +236,7 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, int bias, wmf_plan*
     for (int32_t r : heavy) {
         order[(size_t)fill[WMF_BIN_MFMA]++] = r;
         const int64_t d = indptr[r + 1] - indptr[r];
+        p->heavy_nnz += d;
         for (int64_t off = 0; off < d; off += WMF_SEG) {
             seg_lo.push_back(indptr[r] + off);
             seg_d.push_back((int32_t)(d - off < WMF_SEG ? d - off : WMF_SEG));
@@ -290,10 +291,11 @@ void wmf_plan_destroy(wmf_plan* p) {
     delete p;
 }
 
-int wmf_plan_stats(const wmf_plan* p, int64_t* out8 /* int64[10] */) {
+int wmf_plan_stats(const wmf_plan* p, int64_t* out8 /* int64[12] */) {
     if (!p || !out8) { wmf_set_error("wmf_plan_stats: null"); return WMF_EINVAL; }
     for (int b = 0; b < WMF_NBINS; ++b) { out8[b] = p->count[b]; out8[WMF_NBINS + b] = p->nnz[b]; }
     out8[8] = p->count8; out8[9] = p->nnz8;
+    out8[10] = p->heavy_count; out8[11] = p->heavy_nnz;
     return WMF_OK;
 }
 

@@ -25,7 +25,7 @@ struct wmf_plan {
     int32_t* fallback_count;   // device: 1 counter
     float* w_eff;              // device: nnz effective weights (values - bias[indices]) of a biased model
     // rows of the MFMA bin with more than WMF_HEAVY_T entries sit at the end of that bin and are split into segments
-    int64_t heavy_count, seg_total;
+    int64_t heavy_count, heavy_nnz, seg_total;
     int64_t* seg_lo;           // device: first entry of each segment
     int32_t* seg_d;            // device: entries in each segment
     int32_t* seg_first;        // device: heavy_count + 1 prefix of segment counts

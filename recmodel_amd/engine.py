@@ -91,7 +91,7 @@ class HipKernels:
     def plan_create(self, indptr_host, n, f, bias):
         handle = ctypes.c_void_p()
         _lib.check(self.lib.wmf_plan_create(indptr_host.ctypes.data_as(ctypes.c_void_p), n, f, int(bool(bias)), ctypes.byref(handle)))
-        stats = np.zeros(10, dtype=np.int64)
+        stats = np.zeros(12, dtype=np.int64)
         _lib.check(self.lib.wmf_plan_stats(handle, stats.ctypes.data_as(ctypes.c_void_p)))
         return handle, stats
 
@@ -142,6 +142,7 @@ class Csr:
         self._plan, stats = kernels.plan_create(host_ptr, self.n_rows, f, bias)
         self.bin_rows, self.bin_nnz = stats[:4].copy(), stats[4:8].copy()
         self.rows8, self.nnz8 = int(stats[8]), int(stats[9])           # rows of bin 0 with at most 8 entries
+        self.rows_split, self.nnz_split = int(stats[10]), int(stats[11])   # rows of bin 2 split over several waves
 
     def __del__(self):
         plan, self._plan = getattr(self, "_plan", None), None

@@ -275,8 +275,9 @@ def test_short_rows_share_a_wave(WMF, k, bias, neg):
 def test_many_heavy_rows_per_wave_at_k128(WMF, bias):
     """More heavy rows than resident waves (8000 against 3072), 33 .. 400 entries each, k = 128: every wave of the LDS-DMA
     kernel walks several rows -- next row's metadata requested during the last group, its first rows during the elimination,
-    the metadata buffers rotating across rows -- and must give what the register-ring f32 kernel (debug flag 4096) gives, row
-    by row, and satisfy the rows' own normal equations in float64."""
+    the metadata buffers rotating across rows -- and must give what the ORACLE gives for every one of the 8000 rows (float64
+    restatement of wmf_model.py:220-239 / :337-350), what the register-ring f32 kernel (debug flag 4096) gives, row by row,
+    and satisfy the rows' own normal equations in float64."""
     from recmodel_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(11 + bias)
@@ -298,6 +299,9 @@ def test_many_heavy_rows_per_wave_at_k128(WMF, bias):
     finally:
         lib.wmf_debug_set_flags(0)
     got = step(Y, C, 0.1).astype(np.float64)
+    want = (orc.recompute_factors_bias if bias else orc.recompute_factors)(Y, C.astype(np.float64), 0.1, out_dtype="float64")
+    rel_o, zero_abs = worst_row(got, want)
+    assert fro(got, want) <= HALF_FRO and rel_o <= HALF_ROW and zero_abs == 0.0, (fro(got, want), rel_o)
     rel = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
     assert rel.max() <= 5e-6, (rel.max(), int(rel.argmax()), int(deg[rel.argmax()]))
     Yt, bvec = Y.astype(np.float64).copy(), np.zeros(m_items)

@@ -23,7 +23,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None, backend="gloo"):
+SMALL = (1203, 257, 24, 9)          # users, items, k, mean user degree
+
+
+def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None, backend="gloo", shape=SMALL):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
@@ -35,14 +38,15 @@ def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None,
         from oracle import wmf_oracle as orc
         from recmodel_amd import synth
         from recmodel_amd.engine import AlsEngine
-        n_users, n_items, dim = 1203, 257, 24
-        indptr, indices, counts = synth.make_counts(n_users, n_items, 9, seed=11)
+        n_users, n_items, dim, dbar = shape
+        indptr, indices, counts = synth.make_counts(n_users, n_items, dbar, seed=11)
         values = (10 * torch.log(1 + counts)).to(torch.float32)
         eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cuda:0", chunks=3, reduce_mode=reduce_mode, pipe_mode=pipe_mode,
                         force_exchange=True)
         assert eng.exchange and len(eng.chunk_bounds["users"]) == 3
-        assert eng.reduce["items"] == bool(reduce_mode)
-        eng_pipe_expected = bool(pipe_mode)
+        partial_ok = eng.pr > 0                       # partial systems exist for f <= 144 only: wider models always gather
+        assert eng.reduce["items"] == (bool(reduce_mode) and partial_ok)
+        eng_pipe_expected = bool(pipe_mode) and partial_ok
         eng.set_interactions(indptr, indices, values)
         assert eng.pipe["items"] == eng_pipe_expected and eng.pipe["users"] == eng_pipe_expected
         eng.set_factors("items", orc.init_items(n_items, dim, bias))
@@ -74,11 +78,11 @@ def test_two_ranks_one_gpu_match_oracle(tmp_path, bias, reduce_mode, pipe_mode):
     _check_against_oracle(np.load(out), bias)
 
 
-def _check_against_oracle(got, bias):
+def _check_against_oracle(got, bias, shape=SMALL):
     from oracle import wmf_oracle as orc
     from recmodel_amd import synth
-    n_users, n_items, dim = 1203, 257, 24
-    indptr, indices, counts = synth.make_counts(n_users, n_items, 9, seed=11)
+    n_users, n_items, dim, dbar = shape
+    indptr, indices, counts = synth.make_counts(n_users, n_items, dbar, seed=11)
     raw = synth.to_scipy(indptr, indices, counts, (n_users, n_items))
     C = raw.astype(np.float64)
     C.data = 10 * np.log(1 + C.data)
@@ -103,6 +107,26 @@ def test_one_rank_over_rccl_matches_oracle(tmp_path, bias, reduce_mode, pipe_mod
     out = str(tmp_path / "out.npz")
     mp.spawn(_worker, args=(1, _free_port(), bias, out, reduce_mode, pipe_mode, "nccl"), nprocs=1, join=True)
     _check_against_oracle(np.load(out), bias)
+
+
+@pytest.mark.parametrize("k,bias,mode", [(128, True, "gather"), (128, True, "reduce"), (128, True, "pipe"), (128, False, "pipe"),
+                                         (256, False, "gather"), (256, False, "reduce"), (256, True, "pipe")])
+def test_two_ranks_one_gpu_at_bench_widths(tmp_path, k, bias, mode):
+    """The widths the scaling configurations run at -- k = 128 +- biases (cfg3 / cfg4: LDS-DMA heavy-row kernel, border
+    column, partial systems of 2336+ floats per row) and k = 256 (cfg5: four waves per row; no partial systems, so a
+    requested reduce / pipe mode must fall back to the all-gather) -- under the sharded host path with three chunks per
+    side: chunked CSR views, slot-strided partial systems, the exchange of every mode, against the single-process oracle.
+    Items have ~190 entries each (heavy rows), users ~40 (heavy and 17..32 rows)."""
+    shape = (1203, 257, k, 40)
+    out = str(tmp_path / "out.npz")
+    kw = {"gather": (False, False), "reduce": (True, None), "pipe": (False, True)}[mode]
+    try:
+        mp.spawn(_worker, args=(2, _free_port(), bias, out, kw[0], kw[1], "gloo", shape), nprocs=2, join=True)
+    except Exception as exc:
+        if "gloo" in str(exc).lower() and "cuda" in str(exc).lower():
+            pytest.skip(f"gloo cannot move device tensors here: {exc}")
+        raise
+    _check_against_oracle(np.load(out), bias, shape)
 
 
 def _tiny_worker(rank, world, port, mode, out_path):

@@ -14,7 +14,7 @@ src, prefix = sys.argv[1], sys.argv[2]
 bench_args = sys.argv[3] if len(sys.argv) > 3 else "--steps 5 --warmup 1"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
-OURS = re.compile(r"(gram_|factorize|transform_kernel<\d|solve_|eval_|predict_|confidence_|bias_adjust|spmm_|topk_|score_)")
+OURS = re.compile(r"(gram\d*_|factorize|transform\d*_kernel<\d|solve_|eval_|predict_|confidence_|bias_adjust|spmm_|topk_|score_|csr_)")
 
 
 def short(name):
@@ -41,13 +41,25 @@ with open(os.path.join(out, prefix + "_kernel_stats.csv"), "w", newline="") as f
         r["Percentage"] = f"{100 * float(r['TotalDurationNs']) / total:.2f}"      # share among this library's kernels
         w.writerow(r)
 
+line = open(os.path.join(src, "bench_traced.json")).read().strip().splitlines()[-1]
+traced = json.loads(line)
+# kernels that ran in both half steps of an iteration (bench.py's table): their dispatches alternate users, items
+sides = {}
+for e in traced.get("kernels", []):
+    if e["launches"] == traced["steps"]:               # once per half step (the row transform runs twice: no parity rule)
+        sides.setdefault(e["kernel"], set()).add(e["half_step"])
 raw = json.load(open(os.path.join(src, "traffic_raw.json")))
 kernels = {}
 for name, v in raw.items():
     if not OURS.search(name) or "rocprim" in name:
         continue
     fetch, write = v.get("FETCH_SIZE_KB_per_dispatch_mean"), v.get("WRITE_SIZE_KB_per_dispatch_mean", 0.0)
+    by_side = None
+    fl, wl = v.get("FETCH_SIZE_KB_per_dispatch"), v.get("WRITE_SIZE_KB_per_dispatch")
+    if sides.get(short(name)) == {"users", "items"} and fl and wl and len(fl) == len(wl) and len(fl) % 2 == 0:
+        by_side = {s: (2.0 * sum(fl[i::2]) + sum(wl[i::2])) / (len(fl) // 2) * 1024.0 for i, s in enumerate(("users", "items"))}
     kernels[short(name)] = {
+        "hbm_bytes_by_side": by_side,
         "dispatches": v.get("dispatches"),
         "FETCH_SIZE_KB_mean": fetch, "WRITE_SIZE_KB_mean": write,
         "FETCH_SIZE_KB_largest_dispatch": v.get("FETCH_SIZE_KB_per_dispatch_max"),
@@ -60,8 +72,7 @@ json.dump({
     "correction": "read bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts half of wide/segment reads), write bytes = WRITE_SIZE x 1024",
     "kernels": kernels}, open(os.path.join(out, prefix + "_traffic.json"), "w"), indent=1)
 
-line = open(os.path.join(src, "bench_traced.json")).read().strip().splitlines()[-1]
-json.dump(json.loads(line), open(os.path.join(out, prefix + "_bench_under_rocprof.json"), "w"), indent=1)
+json.dump(traced, open(os.path.join(out, prefix + "_bench_under_rocprof.json"), "w"), indent=1)
 print("wrote", [f for f in sorted(os.listdir(out)) if f.startswith(prefix)])
 for r in mine[:8]:
     print(short(r["Name"]), r["Calls"], f"{float(r['AverageNs']) / 1e6:.3f} ms")

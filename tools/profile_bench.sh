@@ -29,10 +29,12 @@ for name, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
     for f in glob.glob(out + f'/{name}/**/*counter_collection.csv', recursive=True):
         for row in csv.DictReader(open(f)):
             if row['Counter_Name'] == counter:
-                agg[row['Kernel_Name']].append(float(row['Counter_Value']))
+                agg[row['Kernel_Name']].append((int(row['Dispatch_Id']), float(row['Counter_Value'])))
     for k, v in agg.items():
+        v = [x for _, x in sorted(v)]                      # dispatch order: the two half steps of an iteration alternate
         summary.setdefault(k, {})[counter + '_KB_per_dispatch_mean'] = sum(v) / len(v)
         summary[k][counter + '_KB_per_dispatch_max'] = max(v)
+        summary[k][counter + '_KB_per_dispatch'] = v[:64]
         summary[k]['dispatches'] = len(v)
 json.dump(summary, open(out + '/traffic_raw.json', 'w'), indent=1)
 for k, v in summary.items():
