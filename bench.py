@@ -152,6 +152,11 @@ def kernel_work(name, csr, eng, side):
     if name.startswith("solve_rowsplit_kernel") or name.startswith("solve_wide_kernel"):
         return "hbm", nnz[3] * ent_b + rows[3] * row_b
     if name.startswith("gram") and "reduce" not in name:
+        # one pass over the fixed side (B_gram = 4 m f).  The f32-MFMA Gramian (gram_kernel) is priced against
+        # the exact-f32 matrix peak; the split-bf16 one (gram6_kernel, f = 97 .. 144) runs its products at the bf16 rate and
+        # is bound by that read
+        if name.startswith("gram6"):
+            return "hbm", 4.0 * f * eng.n_local[fixed]
         return "mfma", 2.0 * f * f * eng.n_local[fixed]
     return None
 
@@ -324,7 +329,7 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu):
                          "rows_le8": eng.csr[s].rows8, "rows_split": eng.csr[s].rows_split} for s in SIDES},
     }
     if with_cpu:
-        su = args.cpu_users or {64: 300_000, 128: 60_000, 16: 943, 256: 12_000}.get(k, 20_000)
+        su = args.cpu_users or {64: 300_000, 128: 120_000, 16: 943, 256: 12_000}.get(k, 20_000)       # ~10-15 s of NumPy
         su = min(su, n_users_1)
         si = max(1, min(n_items, su * n_items // n_users_1))
         ip = indptr[: su + 1].cpu().numpy()
