@@ -63,16 +63,29 @@ __device__ __forceinline__ f32x2 dl_read2(unsigned addr) {       // dwords at ad
 template <int N>
 __device__ __forceinline__ void dl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// X6: the accumulation B += V_u^T D V_u in split bf16 instead of f32 MFMAs.  Operands are scaled by sqrt(w) and split into
-// three bf16 parts x = hi + mid + lo (the split is exact: 3 x 8 significand bits); per tile and 32 entries six
-// v_mfma_f32_16x16x32_bf16 -- lo.hi, mid.mid, hi.lo, mid.hi, hi.mid, hi.hi, every product exact in f32, the dropped terms
-// below 2^-24 of the product -- replace eight v_mfma_f32_16x16x4_f32 at half the cycles each.  Accuracy of the accumulated
-// tile: 3.1e-7 relative against 2.2e-7 for f32 (tests/scale/proto_split.py: the half step's error is set by the fp32
-// whitening, not here).  A chunk = two ring slots = 32 entries; lane (r, q) takes entries 8 q .. 8 q + 7 of the chunk
-// (the K index of its MFMA operands).  A negative weight has no square root: the NaN it produces reaches the pivot test
-// and the row is bounced to the pivoted kernel, like every system that is not positive definite.
+// X6: the accumulation B += V_u^T D V_u in split f16 instead of f32 MFMAs.  Operands are scaled by DL_S sqrt(w) and split
+// into two f16 parts x = hi + lo (22 significand bits; the f32 remainder is exact, its conversion rounds at 2^-22 of x);
+// per tile and 32 entries three v_mfma_f32_16x16x32_f16 -- lo.hi, hi.lo, hi.hi, every product exact in f32, the dropped
+// lo.lo below 2^-22 of the product -- replace eight v_mfma_f32_16x16x4_f32 at half the cycles each, and the split costs a
+// lane 3 instructions per value (v_cvt_pk_f16_f32 for two, one v_fma_mix per value for the remainder).  The round before
+// used three bf16 parts and six MFMAs (exact split, 9 instructions per value); measured on the CPU prototype
+// (tests/scale/proto_split.py, tests/scale/proto_f16.py) the accumulated tile and the solved row are as accurate as with f32
+// MFMAs either way: the tile's own f32 accumulation, not the 2^-22 of the operands, sets its error.
+// Scale DL_S = 64: whitened factors are small (|v| ~ 1 / sqrt(rows of the fixed side)), and an f16 below 6.1e-5 is a
+// denormal; the factor keeps the low parts of ordinary data normal.  Tiles, right-hand side and border then all carry
+// DL_S^2, which the elimination is told about (its identity is DL_S^2: wmf_dw_elim.h).  Robustness: an operand beyond the f16
+// range (|v sqrt(w)| >= 1024) becomes an infinity whose hi.hi and lo.hi products meet in the diagonal tile as inf - inf, and
+// a negative weight has no square root: either way a NaN reaches the pivot test and the row is bounced to the pivoted
+// kernel, like every system that is not positive definite.  A chunk = two ring slots = 32 entries; lane (r, q) takes
+// entries 8 q .. 8 q + 7 of the chunk (the K index of its MFMA operands).
+#ifndef DL_S
+#define DL_S 64.f
+#endif
+#ifndef DL_LOMODE
+#define DL_LOMODE 0          // lab: 1 = no low parts, 2 = low parts negated
+#endif
 template <int NFB, bool BORDER, bool X6>
 __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(const int32_t* __restrict__ rows, int64_t count, const float* __restrict__ V,
                                                               const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
@@ -320,23 +333,28 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
                 const float wraw = wq[j >> 2][j & 3];
                 wj[j] = real ? wraw : 0.f;
                 pj[j] = real ? wraw + 1.f : 0.f;
-                swj[j] = __builtin_amdgcn_sqrtf(wj[j]);
+                swj[j] = DL_S * __builtin_amdgcn_sqrtf(wj[j]);
                 const float bfv = bq[j >> 2][j & 3];
                 bwj[j] = bfv * wj[j];
                 if constexpr (BORDER) { cacc += bfv * bwj[j]; eacc += bfv * pj[j]; }
             }
-            bf16x8 hi[NFB], mid[NFB], lo3[NFB];
-            auto split = [&](int bj) {                           // right-hand side, border and the three bf16 parts of block bj
+            f16x8 hi[NFB], lo3[NFB];
+            auto split = [&](int bj) {                           // right-hand side, border and the two f16 parts of block bj
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float x = xr[j][bj >> 2][bj & 3];
                     racc[bj] += x * pj[j];
                     if constexpr (BORDER) bacc[bj] += x * bwj[j];
-                    const float sx = x * swj[j];
-                    const __bf16 h = (__bf16)sx;
-                    const float r1 = sx - (float)h;
-                    const __bf16 m = (__bf16)r1;
-                    hi[bj][j] = h; mid[bj][j] = m; lo3[bj][j] = (__bf16)(r1 - (float)m);
+                    {
+                        // No contraction in the split itself: with it hipcc forms the high part twice -- once from the f32
+                        // product (the operand the MFMAs get) and once more inside a v_fma_mix from the unrounded product
+                        // (the one the low part is taken against) -- and the two roundings can disagree by an f16 ulp.
+#pragma clang fp contract(off)
+                        const float sx = x * swj[j];
+                        const _Float16 h = (_Float16)sx;
+                        hi[bj][j] = h;
+                        lo3[bj][j] = DL_LOMODE == 1 ? (_Float16)0.f : (DL_LOMODE == 2 ? (_Float16)((float)h - sx) : (_Float16)(sx - (float)h));
+                    }
                 }
             };
             // Block column by block column, the split of column bj + 1 in front of the MFMAs of column bj, which it does not
@@ -352,12 +370,9 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
                 for (int bi = 0; bi <= bj; ++bi) {
                     const int tt = tile_w<NFB>(bi, bj);
                     f32x4 c = acc[tt];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo3[bi], hi[bj], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[bi], mid[bj], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], lo3[bj], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[bi], hi[bj], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], mid[bj], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], hi[bj], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo3[bi], hi[bj], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi[bi], lo3[bj], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi[bi], hi[bj], c, 0, 0, 0);
                     acc[tt] = c;
                 }
             }
@@ -378,7 +393,18 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
         bool ok = true;
         float gb[NFB];
         float tb = 0.f;
-        dw_eliminate<NFB, BORDER, (DL_GJ_LDS != 0), true>(acc, racc, bacc, cacc, eacc, nullptr, nullptr, r, q, baddr, dbg, gb, tb, ok);
+        if constexpr (X6) {                              // tiles carry DL_S^2 (scaled operands); the VALU sums do not yet
+            constexpr float S2 = DL_S * DL_S;
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) racc[fb] *= S2;
+            if constexpr (BORDER) {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) bacc[fb] *= S2;
+                cacc *= S2; eacc *= S2;
+            }
+        }
+        dw_eliminate<NFB, BORDER, (DL_GJ_LDS != 0), true>(acc, racc, bacc, cacc, eacc, nullptr, nullptr, r, q, baddr, dbg, gb, tb, ok,
+                                                          X6 ? DL_S * DL_S : 1.f);
         if (!ok) {
             if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;
         } else if (q == 0) {

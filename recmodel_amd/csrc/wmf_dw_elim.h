@@ -3,6 +3,8 @@
 // In:  acc[tile_w(bi, bj)] = tile (bi, bj), bi <= bj, of V_u^T D V_u (the identity is added here); racc[fb] = this
 //      lane's share (its q) of (V_u^T p)[16 fb + r]; BORDER: bacc / cacc / eacc = border column, corner, border rhs.
 // Out: gb[p] = g[16 p + (lane & 15)] on every lane, tb = the border unknown, ok = false if a pivot was not positive.
+// diag: what the identity is in the caller's units -- a caller whose tiles, right-hand side and border all carry a common
+//      factor s (accumulated from operands scaled by sqrt(s)) passes diag = s; the solution is the same.
 // Wv / Wb: two LDS vectors of NFB * 16 floats owned by this wave.  NOT __restrict__: lanes r == 0 write them under an exec
 // mask and every lane reads them back; told that nothing else touches the memory, hipcc turns the masked store into
 // load - select - store by ALL lanes, and the lanes that share an address then race with the one real writer.
@@ -25,20 +27,26 @@ __device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for
 template <int NFB, bool BORDER, bool GJ_LDS, bool WREG = false>
 __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], float (&racc)[NFB], float (&bacc)[BORDER ? NFB : 1],
                                              float& cacc, float& eacc, float* Wv, float* Wb, int r,
-                                             int q, const int (&baddr)[4], int dbg, float (&gb)[NFB], float& tb, bool& ok) {
+                                             int q, const int (&baddr)[4], int dbg, float (&gb)[NFB], float& tb, bool& ok,
+                                             const float diag = 1.f) {
     float wvs[WREG ? NFB : 1][4], wbs[(WREG && BORDER) ? NFB : 1][4];
     // ---- C: block elimination, everything in registers except the two panel buffers
     if (!WMF_ABL(dbg, 1)) {
 #pragma unroll
         for (int b = 0; b < NFB; ++b) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) if (r == 4 * q + reg) acc[tile_w<NFB>(b, b)][reg] += 1.f;
+            for (int reg = 0; reg < 4; ++reg) if (r == 4 * q + reg) acc[tile_w<NFB>(b, b)][reg] += diag;
         }
         // LOOK-AHEAD: the inverse of pivot tile p + 1 is started as soon as row p + 1 of the trailing update has been
         // applied, in front of the remaining rows' MFMAs, which it does not depend on: with one wave per SIMD nothing else
         // hides the 16-step dependency chain of the Gauss-Jordan sweep.
         auto invert = [&](int p) {
             f32x4 X = acc[tile_w<NFB>(p, p)];
+            // The sweep's pivot-row update  row += (1 / piv - 1) row  is exact to f32 only for pivots of order one (the
+            // multiplier is rounded at 2^-24 of ONE, not of 1 / piv): a tile that carries the caller's factor `diag` is
+            // brought back to unit scale for the sweep, and its inverse gets the factor once more -- it multiplies tiles
+            // and vectors that still carry `diag`.
+            if (diag != 1.f) X *= 1.f / diag;
 #if WMF_DW_OPAQUE
             // the sweep's lane masks (r == K, q == K / 4) are the same for every pivot; hipcc hoists all 36 of them out of
             // the pivot loop and then spills them to VGPR lanes (v_writelane / v_readlane pairs around every use).  Lane
@@ -50,6 +58,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
 #else
             gj_inv_sweep<GJ_LDS, true>(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
 #endif
+            if (diag != 1.f) X *= 1.f / diag;
             return X;
         };
         f32x4 Xnext = invert(0);
@@ -124,7 +133,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
     if constexpr (BORDER) {
         cacc += __shfl_xor(cacc, 16); cacc += __shfl_xor(cacc, 32);
         eacc += __shfl_xor(eacc, 16); eacc += __shfl_xor(eacc, 32);
-        const float piv = 1.f + cacc;                       // identity + c - sum_p b_p^T w^b_p
+        const float piv = diag + cacc;                      // identity + c - sum_p b_p^T w^b_p
         if (!(piv > 1e-20f)) ok = false;
         tb = eacc * __builtin_amdgcn_rcpf(piv);
     }

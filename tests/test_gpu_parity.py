@@ -302,8 +302,10 @@ def test_many_heavy_rows_per_wave_at_k128(WMF, bias):
     want = (orc.recompute_factors_bias if bias else orc.recompute_factors)(Y, C.astype(np.float64), 0.1, out_dtype="float64")
     rel_o, zero_abs = worst_row(got, want)
     assert fro(got, want) <= HALF_FRO and rel_o <= HALF_ROW and zero_abs == 0.0, (fro(got, want), rel_o)
+    # the two kernels differ in arithmetic (split-f16 products with an LDS-DMA ring here, f32 MFMAs from a register ring
+    # there): they agree to the accuracy either has against the oracle, far inside the row tolerance
     rel = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
-    assert rel.max() <= 5e-6, (rel.max(), int(rel.argmax()), int(deg[rel.argmax()]))
+    assert rel.max() <= 0.2 * HALF_ROW, (rel.max(), int(rel.argmax()), int(deg[rel.argmax()]))
     Yt, bvec = Y.astype(np.float64).copy(), np.zeros(m_items)
     if bias:
         bvec, Yt[:, 0] = Yt[:, 0].copy(), 1.0
