@@ -28,12 +28,13 @@ def regs_of(text):
 
 bad = reads = 0
 inflight = {}          # register -> line number of the read that targets it
+order = []             # in-flight reads, oldest first: (line, registers); LDS reads retire in issue order
 in_asm = False
 kernel = None
 for n, ln in enumerate(lines, 1):
     t = ln.strip()
     if t.startswith("_Z") and t.endswith(":") or re.match(r"^_Z\w+:", t):
-        kernel, inflight = t.split(":")[0], {}
+        kernel, inflight, order = t.split(":")[0], {}, []
     if t.startswith(";;#ASMSTART"):
         in_asm = True
         continue
@@ -47,13 +48,16 @@ for n, ln in enumerate(lines, 1):
         dst = code.split(",")[0]
         for r in regs_of(dst):
             inflight[r] = n
+        order.append((n, regs_of(dst)))
         reads += 1
         continue
-    if in_asm and code.startswith("s_waitcnt") and "lgkmcnt(0)" in code:
-        inflight = {}
-        continue
-    if "s_waitcnt" in code and "lgkmcnt(0)" in code:       # a compiler wait retires them as well
-        inflight = {}
+    m_wait = re.search(r"lgkmcnt\((\d+)\)", code) if code.startswith("s_waitcnt") else None
+    if m_wait and (in_asm or int(m_wait.group(1)) == 0):
+        # a counted wait of the kernel's own (inline asm) leaves its N youngest reads in flight; a compiler wait is only
+        # trusted when it drains the counter (its counts do not include the inline-asm reads)
+        keep = int(m_wait.group(1))
+        order = order[len(order) - keep:] if keep else []
+        inflight = {r: ln_ for ln_, regs in order for r in regs}
         continue
     touched = regs_of(code) & set(inflight)
     if touched and code.strip().startswith("v_pk_"):
