@@ -84,8 +84,10 @@ int wmf_factorize(const double* G_sum, int f, int ld, double lambda,
                   void* workspace, void* stream);
 
 /* out[r, :] = in~[r, :] . W  for rows [0, m), in/out [m, ld], W [f, ld].
- * set_col0_one != 0: in~ is `in` with column 0 read as 1, and in[r,0] is copied to
- * col0_out[r] (the fixed side's bias vector, wmf_model.py:328-331).  col0_out may be NULL. */
+ * set_col0_one != 0 (whitening of the fixed side of a bias model): in~ is `in` with column 0 read as 1, and the bias
+ * in[r,0] (wmf_model.py:328-331) is copied to col0_out[r] (may be NULL) AND, for the widths f = 16 m + 1 <= 144 with
+ * ld = f + 3 (k = 16, 32, 64, 80, 96, 128 with biases), to out[r, f], the first padding column of the whitened row --
+ * where the row kernels of wmf_solve_rows pick it up together with the row itself.  All other padding is written as zero. */
 int wmf_row_transform(const float* in, int64_t m, int f, int ld, const float* W,
                       int set_col0_one, float* out, float* col0_out, void* stream);
 
@@ -104,7 +106,9 @@ int  wmf_plan_stats(const wmf_plan* p, int64_t* out12);
 
 /* The per-row normal-equation solve in whitened coordinates, for every row of the CSR:
  *   g_u = (I + V_u^T D_u V_u)^-1 V_u^T (w_u + 1),   V_u = V[idx_u], D_u = diag(w_u)
- * with w_u = values - bias_fixed[idx_u] when bias_fixed != NULL (wmf_model.py:343).
+ * with w_u = values - bias_fixed[idx_u] when bias_fixed != NULL (wmf_model.py:343).  V and bias_fixed must both come
+ * from wmf_row_transform(set_col0_one = 1) on the same matrix: for the widths named there the kernels read the bias
+ * from V[idx, f] and never touch bias_fixed (which then only says "this is a bias model").
  * g [n, ld]; follow with wmf_row_transform(g, W_unwhite) to obtain X_new.
  * Restates the loop body wmf_model.py:220-239 / 337-350.  Rows without stored entries give 0.
  * fail_count (device int32, caller zeroes): number of rows whose system was numerically singular. */

@@ -760,6 +760,7 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
             }
             if (t == 0 && set_col0_one && q == 0) {
                 if (rok && col0_out && NB0 == 0) col0_out[row] = xe[0];
+                if (rok && set_col0_one == 2 && NB0 == 0) out[row * (int64_t)ld + f] = xe[0];   // the bias rides in the row's first padding column
                 xe[0] = 1.f;
             }
             unsigned mv = tmask[t];
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb) {
                     const int col = 16 * (NB0 + nb) + r;
-                    if (col < ld) o[col] = acc[nb][reg];
+                    if (col < ld && !(set_col0_one == 2 && col == f)) o[col] = acc[nb][reg];     // (column f: the bias, stored above)
                 }
             }
         }
@@ -889,6 +890,7 @@ __global__ __launch_bounds__(512) void transform6_kernel(const float* __restrict
             }
             if (c == 0 && set_col0_one && q == 0) {
                 if (rok && col0_out) col0_out[row] = xe[0];
+                if (rok && set_col0_one == 2) out[row * (int64_t)ld + f] = xe[0];    // the bias rides in the row's first padding column
                 xe[0] = 1.f;
             }
             bf16x8_t ah, am, al;
@@ -926,7 +928,7 @@ __global__ __launch_bounds__(512) void transform6_kernel(const float* __restrict
 #pragma unroll
                 for (int nb = 0; nb < NFB; ++nb) {
                     const int col = 16 * nb + r;
-                    if (col < ld) o[col] = acc[nb][reg];
+                    if (col < ld && !(set_col0_one == 2 && col == f)) o[col] = acc[nb][reg];     // (column f: the bias, stored above)
                 }
             }
         }
@@ -1010,6 +1012,9 @@ int wmf_launch_transform(const float* in, int64_t m, int f, int ld, const float*
                          float* col0_out, hipStream_t st) {
     if (m <= 0) return 0;
     const int nfb = (f + 15) / 16;
+    // set_col0_one == 2 inside the kernels: the bias also goes to column f of the output row (wmf_bias_in_pad widths only:
+    // elsewhere the row kernels gather that column as data and rely on its being zero)
+    set_col0_one = set_col0_one ? (wmf_bias_in_pad(f, ld) ? 2 : 1) : 0;
     switch (nfb) {
 #define C(N) case N: launch_transform_nfb<N>(in, m, f, ld, W, set_col0_one, out, col0_out, st); break;
         C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)

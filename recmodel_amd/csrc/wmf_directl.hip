@@ -30,13 +30,14 @@
 #define DL_GJ_LDS 0                 // multiplier column of the tile inverse: 1 = ds_bpermute, 0 = two VALU lane swaps
 #endif
 #define DL_R 4                      // ring slots = groups per 64-entry block (the group loop is unrolled by it)
-#define DL_W 1024                   // metadata behind the ring: idx[4][64], w[4][64], border[4][64], block b in buffer b & 3
+#define DL_W 1024                   // metadata behind the ring: idx[4][64], w[4][64], border[4][64], bias[4][64], block b in buffer b & 3
 #define DL_BD 2048                  // (block b + 1 is requested while groups of b - 1 are still being consumed: three live blocks)
+#define DL_BB 3072                  // the fixed side's bias of the entries: V[idx][f], behind the border feature V[idx][f - 1]
 // per width (NFB = 4: f = 64 / 65, NFB = 8: f = 128 / 129): bytes of the feature part of a row, of a 16-entry slot, of the ring
 #define DL_RB(NFB) (64 * (NFB))
 #define DL_SLOTB(NFB) (16 * DL_RB(NFB))
 #define DL_METAB(NFB) (DL_R * DL_SLOTB(NFB))
-#define DL_LDSB(NFB) (DL_METAB(NFB) + 3 * 1024)
+#define DL_LDSB(NFB) (DL_METAB(NFB) + 4 * 1024)
 
 typedef const __attribute__((address_space(1))) void* dl_gptr;
 typedef __attribute__((address_space(3))) void* dl_lptr;
@@ -90,7 +91,8 @@ template <int NFB, bool BORDER, bool X6>
 __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(const int32_t* __restrict__ rows, int64_t count, const float* __restrict__ V,
                                                               const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                               const float* __restrict__ vals, int f, int ld, float* __restrict__ g,
-                                                              int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int dbg) {
+                                                              int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int dbg,
+                                                              int bias_in_pad) {
     constexpr int NT = NFB * (NFB + 1) / 2;
     constexpr int RB = DL_RB(NFB), DL_SLOT = DL_SLOTB(NFB), DL_META = DL_METAB(NFB);   // row bytes, slot bytes, metadata offset
     constexpr int J = NFB / 4;                  // 16-byte pieces per lane and entry (pieces r, r + 16, ..)
@@ -141,6 +143,10 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(iv)::"memory");     // the value passes through the wait: no use can move above it
             const int idx = __builtin_bit_cast(int, iv);
             __builtin_amdgcn_global_load_lds((dl_gptr)(V + (int64_t)idx * ld + 16 * NFB), (dl_lptr)(smem + DL_META + DL_BD + par), 4, 0, 0);
+            // the fixed side's bias, one float further (wmf_bias_in_pad): same 128-byte line, so a second dword of a request the
+            // border makes anyway.  (A bias vector gathered here instead cost what the separate bias_adjust pass costs.)
+            if (bias_in_pad)
+                __builtin_amdgcn_global_load_lds((dl_gptr)(V + (int64_t)idx * ld + 16 * NFB + 1), (dl_lptr)(smem + DL_META + DL_BB + par), 4, 0, 0);
         }
     };
     // the 16 rows of group gi (S = gi % 4 = its ring slot and its position in the block) -> 8 DMA instructions
@@ -233,21 +239,24 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             // LDS operands of k-step t + 1 are requested before the MFMAs of k-step t (only the first k-step of a group
             // waits for its own reads with nothing to do)
             f32x4 xa[2], xb[2];
-            float wv[2], bf[2] = {0.f, 0.f};
+            float wv[2], bf[2] = {0.f, 0.f}, bb[2] = {0.f, 0.f};
             auto request = [&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 xa[t & 1] = dl_read128<S * DL_SLOT + t * 4 * RB>(ring_rd);
                 if constexpr (J == 2) xb[t & 1] = dl_read128<S * DL_SLOT + t * 4 * RB + 256>(ring_rd);
                 else xb[t & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 wv[t & 1] = dl_read32<DL_W + (S * 16 + 4 * t) * 4>(meta_rd + par);
-                if constexpr (BORDER) bf[t & 1] = dl_read32<DL_BD + (S * 16 + 4 * t) * 4>(meta_rd + par);
+                if constexpr (BORDER) {
+                    bf[t & 1] = dl_read32<DL_BD + (S * 16 + 4 * t) * 4>(meta_rd + par);
+                    bb[t & 1] = dl_read32<DL_BB + (S * 16 + 4 * t) * 4>(meta_rd + par);      // (zeros, or stale finite data, without biases)
+                }
             };
             auto kstep = [&](auto tc) {
                 constexpr int t = decltype(tc)::value, B = t & 1;
                 if (t >= nk) return;                             // wave-uniform: past the row's end
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[B]), "+v"(xb[B]), "+v"(wv[B]), "+v"(bf[B])::"memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[B]), "+v"(xb[B]), "+v"(wv[B]), "+v"(bf[B]), "+v"(bb[B])::"memory");
                 const f32x4 ya = xa[B], yb = xb[B];
-                const float wraw = wv[B], bfv = bf[B];
+                const float wraw = (BORDER && bias_in_pad) ? wv[B] - bb[B] : wv[B], bfv = bf[B];
                 if constexpr (t < 3) { if (t + 1 < nk) request(std::integral_constant<int, t + 1>{}); }
                 const bool real = 16 * G + 4 * t + q < d;
                 const float w = real ? wraw : 0.f, p = real ? wraw + 1.f : 0.f;
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             else dl_wait_vm<0>();
             // all LDS operands of the chunk into registers: 8 entries x 2 pieces, their weights and border values
             const unsigned par = ((mb + (G >> 2)) & 3) * 256;
-            f32x4 xr[8][2], wq[2], bq[2];
+            f32x4 xr[8][2], wq[2], bq[2], bbq[2];
             auto read_entry = [&](auto jc) {
                 constexpr int jj = decltype(jc)::value;
                 xr[jj][0] = dl_read128<S * DL_SLOT + jj * RB>(ring6_rd);
@@ -305,13 +314,15 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             if constexpr (BORDER) {
                 bq[0] = dl_read128<DL_BD + S * 64>(meta6_rd + par);
                 bq[1] = dl_read128<DL_BD + S * 64 + 16>(meta6_rd + par);
+                bbq[0] = dl_read128<DL_BB + S * 64>(meta6_rd + par);
+                bbq[1] = dl_read128<DL_BB + S * 64 + 16>(meta6_rd + par);
             } else {
-                bq[0] = bq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bq[0] = bq[1] = bbq[0] = bbq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(xr[0][0]), "+v"(xr[0][1]), "+v"(xr[1][0]), "+v"(xr[1][1]), "+v"(xr[2][0]), "+v"(xr[2][1]), "+v"(xr[3][0]),
                            "+v"(xr[3][1]), "+v"(xr[4][0]), "+v"(xr[4][1]), "+v"(xr[5][0]), "+v"(xr[5][1]), "+v"(xr[6][0]), "+v"(xr[6][1]),
-                           "+v"(xr[7][0]), "+v"(xr[7][1]), "+v"(wq[0]), "+v"(wq[1]), "+v"(bq[0]), "+v"(bq[1])::"memory");
+                           "+v"(xr[7][0]), "+v"(xr[7][1]), "+v"(wq[0]), "+v"(wq[1]), "+v"(bq[0]), "+v"(bq[1]), "+v"(bbq[0]), "+v"(bbq[1])::"memory");
             // the two slots are free again: request groups G + 4, G + 5 into them (the first of them opens a block when S == 0)
             if (G + 4 < ngroups) {
                 if constexpr (S == 0) {
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const bool real = 16 * G + 8 * q + j < d;
-                const float wraw = wq[j >> 2][j & 3];
+                const float wraw = (BORDER && bias_in_pad) ? wq[j >> 2][j & 3] - bbq[j >> 2][j & 3] : wq[j >> 2][j & 3];
                 wj[j] = real ? wraw : 0.f;
                 pj[j] = real ? wraw + 1.f : 0.f;
                 swj[j] = DL_S * __builtin_amdgcn_sqrtf(wj[j]);
@@ -427,8 +438,9 @@ int wmf_directl_supported(int f, int ld) {
     return (f == 128 && ld == 128) || (f == 129 && ld == 132) || (f == 64 && ld == 64) || (f == 65 && ld == 68);
 }
 
-int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const int64_t* indptr, const int32_t* indices,
-                       const float* vals, int f, int ld, float* g, int32_t* fb_rows, int32_t* fb_count, hipStream_t st) {
+int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, bool bias_in_pad, const int64_t* indptr,
+                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows, int32_t* fb_count,
+                       hipStream_t st) {
     if (count <= 0) return 0;
     if (!wmf_directl_supported(f, ld)) return -1;
     const int nfb = f / 16;                                      // 4 or 8 (the bias column is a border)
@@ -437,7 +449,7 @@ int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const
     const int dbg = wmf_debug_flags;
     const bool x6 = !(dbg & 8192);                              // debug flag 8192: f32 MFMA accumulation
 #define DL_LAUNCH(N, B, X) WMF_LAUNCH("solve_directl_kernel<" #N ", " #B ", " #X ">", (solve_directl_kernel<N, B, X>), grid, dim3(64), \
-                                      DL_LDSB(N), st, rows, count, V, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg)
+                                      DL_LDSB(N), st, rows, count, V, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, (int)bias_in_pad)
 #define DL_PICK(N) do { if (f % 16) { if (x6) DL_LAUNCH(N, true, true); else DL_LAUNCH(N, true, false); } \
                         else        { if (x6) DL_LAUNCH(N, false, true); else DL_LAUNCH(N, false, false); } } while (0)
     if (nfb == 4) DL_PICK(4); else DL_PICK(8);

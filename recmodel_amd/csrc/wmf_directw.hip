@@ -157,15 +157,26 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                 for (int t = 0; t < GS; ++t) {
                     float fw[NFB];
                     st.template mask_tail<S>(t, ld, r);
+                    float wt = st.w[S][t], pt = st.p[S][t];
+                    if constexpr (BORDER) {
+                        // biasv != NULL: the fixed side's bias sits behind the border feature, in the row's first padding column
+                        // (wmf_bias_in_pad) -- the dword block that brings the border to lane r = 0 brings it to lane r = 1
+                        if (biasv) {
+                            const bool real = Stream::EPG * G + 4 * t + q < d;
+                            const float bs = real ? wmf_dpp<0x151>(st.fr[S][t][NFB]) : 0.f;     // row_newbcast:1
+                            wt -= bs;
+                            pt -= bs;
+                        }
+                    }
 #pragma unroll
-                    for (int fb = 0; fb < NFB; ++fb) { fw[fb] = st.fr[S][t][fb] * st.w[S][t]; racc[fb] += st.fr[S][t][fb] * st.p[S][t]; }
+                    for (int fb = 0; fb < NFB; ++fb) { fw[fb] = st.fr[S][t][fb] * wt; racc[fb] += st.fr[S][t][fb] * pt; }
                     if constexpr (BORDER) {
                         const float bf = wmf_dpp<0x150>(st.fr[S][t][NFB]);          // border feature of this lane's entry (row_newbcast:0)
-                        const float bw = bf * st.w[S][t];
+                        const float bw = bf * wt;
 #pragma unroll
                         for (int fb = 0; fb < NFB; ++fb) bacc[fb] += st.fr[S][t][fb] * bw;
                         cacc += bf * bw;
-                        eacc += bf * st.p[S][t];
+                        eacc += bf * pt;
                     }
                     int tt = 0;
 #pragma unroll
@@ -284,8 +295,9 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
     const int64_t normal = pl->count[WMF_BIN_MFMA] - pl->heavy_count;
     // k = 128 with or without biases: the LDS-DMA ring kernel (wmf_directl.hip); debug flag 4096 keeps the register ring
     // (f = 64 / 65 can run there too, debug flag 65536, but gains nothing: cfg2 item side 1.34 ms against 1.30 here)
-    if (normal > 0 && biasv == nullptr && wmf_directl_supported(f, ld) && !(dbg & 4096) && (f >= 128 || (dbg & 65536))) {
-        (void)wmf_launch_directl(rows, normal, V, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, st);
+    // (biasv is NULL here, or V + f with the bias in the rows' padding: both kernels take the bias from the row itself)
+    if (normal > 0 && wmf_directl_supported(f, ld) && !(dbg & 4096) && (f >= 128 || (dbg & 65536))) {
+        (void)wmf_launch_directl(rows, normal, V, biasv != nullptr, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, st);
     } else if (normal > 0) {
         static const char* nm = wmf_kname("solve_directw_kernel<%d, 0, %s>", NFB, BORDER ? "true" : "false");
         WMF_LAUNCH(nm, (solve_directw_kernel<NFB, 0, BORDER>), dim3((unsigned)(normal < cap ? normal : cap)), dim3(64), 0, st,
@@ -327,7 +339,7 @@ static void launch_eliminate_nfb(float* partial, int64_t n, int slots_per_row, i
                nullptr, nullptr, nullptr, nullptr, nullptr, f, ld, g, fb_rows, fail_count, wmf_debug_flags & ~3, nullptr,
                nullptr, nullptr, partial, slots_per_row, 0);
 }
-static bool dw_border(int f) { return f > 16 && f % 16 == 1 && (f / 16) % 4 != 3 && !(wmf_debug_flags & 256); }
+static bool dw_border(int f) { return wmf_dw_border(f); }
 
 int64_t wmf_directw_partial_floats(int f) {
     if (f < 1 || f > 144) return 0;

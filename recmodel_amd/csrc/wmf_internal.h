@@ -9,6 +9,8 @@
 #define WMF_SEG 2048          /* ... in segments of this many entries */
 #define WMF_WIDE_LU_GRID 64   /* workgroups (and workspace slices) of the pivoted-LU fallback for f > 144 */
 
+extern int wmf_debug_flags;   // kernel-selection switches for timing experiments (tools/kernel_lab.py); 0 in normal use
+
 // row-degree bins of a plan
 enum { WMF_BIN_LOW16 = 0, WMF_BIN_LOW32 = 1, WMF_BIN_MFMA = 2, WMF_BIN_GENERAL = 3, WMF_NBINS = 4 };
 
@@ -46,10 +48,18 @@ int wmf_launch_solve(const wmf_plan* plan, const float* V, const float* bias_fix
                      const int32_t* indices, const float* values, int f, int ld, float* g, int32_t* fail_count,
                      hipStream_t st);
 static inline int wmf_direct_supported(int f) { return f >= 1 && f <= 144; }   // one wave per row holds the f x f system
+// Widths whose last feature is a border column of an m-block system (f = 16 m + 1 <= 144, m + 1 not a multiple of 4; debug
+// flag 256 switches the border off): k = 16 m with biases.
+static inline bool wmf_dw_border(int f) { return f > 16 && f <= 144 && f % 16 == 1 && (f / 16) % 4 != 3 && !(wmf_debug_flags & 256); }
+// For those widths the whitened row V[i] (ld = f + 3 floats) carries its side's bias in the first padding column, V[i][f]
+// (written by wmf_row_transform(set_col0_one = 1)): the row kernels subtract it from the entry weights as the row arrives
+// (RecModel/wmf_model.py:343) instead of a separate pass over all entries that gathers it from a bias vector.
+static inline bool wmf_bias_in_pad(int f, int ld) { return wmf_dw_border(f) && ld == f + 3; }
 // wmf_directl.hip: normal heavy rows at f = 128 / 129 through an LDS-DMA row ring
 int wmf_directl_supported(int f, int ld);
-int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const int64_t* indptr, const int32_t* indices,
-                       const float* vals, int f, int ld, float* g, int32_t* fb_rows, int32_t* fb_count, hipStream_t st);
+int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, bool bias_in_pad, const int64_t* indptr,
+                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows, int32_t* fb_count,
+                       hipStream_t st);
 int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int f, int ld, float* g, hipStream_t st);
 int64_t wmf_directw_partial_floats(int f);
@@ -93,7 +103,6 @@ int wmf_launch_rank_batch(const float* users, const float* items, int f, int ld,
 int wmf_launch_confidence(float* values, int64_t nnz, double alpha, double beta, int mode, hipStream_t st);
 
 void wmf_set_error(const char* fmt, ...);
-extern int wmf_debug_flags;   // kernel-selection switches for timing experiments (tools/kernel_lab.py); 0 in normal use
 // Ablation switches whose results are WRONG (1 no elimination, 2 no accumulation MFMAs, 8 no tile inverse) are compiled
 // into a -DWMF_LAB build only (tools/build_variant.sh); the shipped library has no such code path.
 #ifdef WMF_LAB

@@ -97,7 +97,10 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
                                                         const int64_t* __restrict__ indptr,
                                                         const int32_t* __restrict__ indices,
                                                         const float* __restrict__ vals, int ld, int last1, float* __restrict__ g,
-                                                        int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count) {
+                                                        int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int bstride) {
+    // biasv / bstride: the fixed side's bias of row idx is biasv[idx * bstride] -- a bias vector (bstride = 1), or the first
+    // padding column of the whitened rows themselves (biasv = V + f, bstride = ld: wmf_bias_in_pad), which the gathers
+    // below then have to keep out of the products
     const int lane = threadIdx.x & 63;
     // wave-uniform values are forced into SGPRs: hipcc cannot see that threadIdx.x >> 6 is uniform, and
     // would otherwise predicate every `k < d` step with exec masks and register copies
@@ -130,11 +133,7 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
         const int64_t e = j < d ? lo + j : 0;       // entry 0 exists: the launcher skips matrices without entries
         const int idx = indices[e];
         float wj = vals[e];
-        if (biasv) wj -= biasv[idx];
-        wj *= am;
-        if (!(wj >= 0.f)) neg = true;               // negative or NaN weight: needs pivoting
-        w[s] = wj;
-        p[s] = wj + am;
+        if (biasv && bstride == 1) wj -= biasv[idx];
         const float4* vrow = Vq + (int64_t)idx * nch;
         if constexpr (X6) {                          // pieces 8 c + 2 q + h, all inside the row (ld is a multiple of 32)
 #pragma unroll
@@ -143,8 +142,17 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
 #pragma unroll
             for (int t = 0; t < NCH - 1; ++t) x[s][t] = vrow[4 * t];
             const float4 v = (vrow - q)[last_c];
-            x[s][NCH - 1] = make_float4(v.x * last_m, v.y * last_m, v.z * last_m, v.w * last_m);
+            // Bias in the padding (bstride > 1): f = 4 (nch - 1) + 1, the row's last piece is { feature f - 1, bias, 0, 0 }, and
+            // it is the piece EVERY lane of the entry has just loaded (q = 0 owns it, the others were clamped to it): the
+            // bias costs no load of its own.
+            const float pad_m = (bstride > 1) ? 0.f : last_m;
+            if (bstride > 1) wj -= v.y;
+            x[s][NCH - 1] = make_float4(v.x * last_m, v.y * pad_m, v.z * last_m, v.w * last_m);
         }
+        wj *= am;
+        if (!(wj >= 0.f)) neg = true;               // negative or NaN weight: needs pivoting
+        w[s] = wj;
+        p[s] = wj + am;
     }
     if (__any(neg)) {                               // wave-uniform: bounce the row to the LU kernel
         if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(256, NCH <= 9 ? 6 : 1) void solve_pair_kernel(const
                                                                           const int64_t* __restrict__ indptr,
                                                                           const int32_t* __restrict__ indices,
                                                                           const float* __restrict__ vals, int ld, int last1, float* __restrict__ g,
-                                                                          int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count) {
+                                                                          int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int bstride) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t pid = (int64_t)blockIdx.x * 4 + wave;
@@ -380,10 +388,7 @@ __global__ __launch_bounds__(256, NCH <= 9 ? 6 : 1) void solve_pair_kernel(const
     const int64_t e = j < my_d ? (second ? loB : loA) + j : 0;     // entry 0 exists: the launcher skips matrices without entries
     const int idx = indices[e];
     float wj = vals[e];
-    if (biasv) wj -= biasv[idx];
-    wj *= am;
-    const bool neg = !(wj >= 0.f);                   // negative or NaN weight: needs pivoting
-    float w[1] = {wj}, p[1] = {wj + am};
+    if (biasv && bstride == 1) wj -= biasv[idx];
     float4 x[NCH];
     const float4* Vq = reinterpret_cast<const float4*>(V) + q;
     const int last_c = min(4 * (NCH - 1) + q, nch - 1);
@@ -393,8 +398,13 @@ __global__ __launch_bounds__(256, NCH <= 9 ? 6 : 1) void solve_pair_kernel(const
     for (int t = 0; t < NCH - 1; ++t) x[t] = vrow[4 * t];
     {
         const float4 v = (vrow - q)[last_c];
-        x[NCH - 1] = make_float4(v.x * last_m, v.y * last_m, v.z * last_m, v.w * last_m);
+        const float pad_m = (bstride > 1) ? 0.f : last_m;    // (bias in the padding: every lane holds it in v.y, see solve_low_kernel)
+        if (bstride > 1) wj -= v.y;
+        x[NCH - 1] = make_float4(v.x * last_m, v.y * pad_m, v.z * last_m, v.w * last_m);
     }
+    wj *= am;
+    const bool neg = !(wj >= 0.f);                   // negative or NaN weight: needs pivoting
+    float w[1] = {wj}, p[1] = {wj + am};
     auto bounce = [&]() {                            // both rows go to the pivoted LU kernel
         if (lane == 0) {
             const int at = atomicAdd(fb_count, hasB ? 2 : 1);
@@ -451,7 +461,9 @@ __global__ __launch_bounds__(256) void solve_general_kernel(const int32_t* __res
                                                             const int64_t* __restrict__ indptr,
                                                             const int32_t* __restrict__ indices,
                                                             const float* __restrict__ vals, int f, int ld,
-                                                            float* __restrict__ g, int32_t* __restrict__ fail_count) {
+                                                            float* __restrict__ g, int32_t* __restrict__ fail_count, int bstride) {
+    // (bias in the padding, bstride = ld: column f of the staged rows holds it; only the leading f x f block and the first f
+    // entries of the right-hand side are ever used)
     constexpr int FP = 16 * NFB;
     constexpr int LDV = FP + 4;          // staging row stride (floats), keeps 16-byte alignment
     constexpr int LDB = FP + 1;          // odd: conflict-free column walks
@@ -491,7 +503,7 @@ __global__ __launch_bounds__(256) void solve_general_kernel(const int32_t* __res
             if (tid < nrow) {
                 const int idx = indices[lo + base + tid];
                 float wj = vals[lo + base + tid];
-                if (biasv) wj -= biasv[idx];
+                if (biasv) wj -= biasv[(int64_t)idx * bstride];
                 ws[tid] = wj;
             }
             __syncthreads();
@@ -632,7 +644,7 @@ void wmf_launch_bias_adjust(const float* vals, const int32_t* indices, const flo
 
 // ------------------------------------------------------------------------------------- launchers
 template <int NCH>
-static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
+static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, int bstride, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int ld, int last1, float* g, hipStream_t st) {
     const int64_t c0 = pl->count[WMF_BIN_LOW16], c1 = pl->count[WMF_BIN_LOW32];
     // rows with at most 8 entries come first in the bin and go two per wave (solve_pair_kernel)
@@ -642,14 +654,14 @@ static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, c
         WmfProfScope ps(nm, st);
         hipLaunchKernelGGL((solve_pair_kernel<NCH>), dim3((unsigned)(((c8 + 1) / 2 + 3) / 4)), dim3(256), 0, st,
                            pl->rows[WMF_BIN_LOW16], c8, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
-                           pl->fallback_count);
+                           pl->fallback_count, bstride);
     }
     if (c0 - c8 > 0) {
         static const char* nm = wmf_kname("solve_low_kernel<%d, 1, false, false>", NCH);
         WmfProfScope ps(nm, st);
         hipLaunchKernelGGL((solve_low_kernel<NCH, 1, false>), dim3((unsigned)((c0 - c8 + 3) / 4)), dim3(256), 0, st,
                            pl->rows[WMF_BIN_LOW16] + c8, c0 - c8, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
-                           pl->fallback_count);
+                           pl->fallback_count, bstride);
     }
     if (c1 > 0) {
         static const char* nm_gj = wmf_kname("solve_low_kernel<%d, 2, false, false>", NCH);
@@ -660,22 +672,22 @@ static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, c
         if (wmf_debug_flags & 64)       // plain 32 x 32 Gauss-Jordan, kept for A/B timing
             hipLaunchKernelGGL((solve_low_kernel<NCH, 2, false>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
                                pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
-                               pl->fallback_count);
+                               pl->fallback_count, bstride);
         else if (NCH % 2 == 0 && ld % 32 == 0 && !(wmf_debug_flags & 524288)) {    // split-bf16 S tiles (flag 524288: f32)
             if constexpr (NCH % 2 == 0)
                 hipLaunchKernelGGL((solve_low_kernel<NCH, 2, true, true>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
                                    pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
-                                   pl->fallback_count);
+                                   pl->fallback_count, bstride);
         } else
             hipLaunchKernelGGL((solve_low_kernel<NCH, 2, true>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
                                pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
-                               pl->fallback_count);
+                               pl->fallback_count, bstride);
     }
 }
 
 template <int NFB>
 static void launch_general(const int32_t* rows, int64_t count, const int32_t* count_ptr, int grid, const float* V,
-                           const float* biasv, const int64_t* indptr, const int32_t* indices, const float* vals, int f,
+                           const float* biasv, int bstride, const int64_t* indptr, const int32_t* indices, const float* vals, int f,
                            int ld, float* g, int32_t* fail_count, hipStream_t st) {
     constexpr int FP = 16 * NFB;
     constexpr size_t lds = ((size_t)16 * (FP + 4) + 16 + FP + 8 + (size_t)FP * (FP + 1)) * 4;
@@ -687,14 +699,14 @@ static void launch_general(const int32_t* rows, int64_t count, const int32_t* co
     }
     static const char* nm = wmf_kname("solve_general_kernel<%d>", NFB);
     WMF_LAUNCH(nm, (solve_general_kernel<NFB>), dim3(grid), dim3(256), lds, st, rows, count, count_ptr, V, biasv,
-               indptr, indices, vals, f, ld, g, fail_count);
+               indptr, indices, vals, f, ld, g, fail_count, bstride);
 }
 
 static int dispatch_general(const int32_t* rows, int64_t count, const int32_t* count_ptr, int grid, const float* V,
-                            const float* biasv, const int64_t* indptr, const int32_t* indices, const float* vals, int f,
+                            const float* biasv, int bstride, const int64_t* indptr, const int32_t* indices, const float* vals, int f,
                             int ld, float* g, int32_t* fail_count, hipStream_t st) {
     switch ((f + 15) / 16) {
-#define C(N) case N: launch_general<N>(rows, count, count_ptr, grid, V, biasv, indptr, indices, vals, f, ld, g, fail_count, st); break;
+#define C(N) case N: launch_general<N>(rows, count, count_ptr, grid, V, biasv, bstride, indptr, indices, vals, f, ld, g, fail_count, st); break;
         C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9)
 #undef C
         default: return -1;
@@ -709,13 +721,17 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
     const int64_t nnz = pl->nnz[0] + pl->nnz[1] + pl->nnz[2] + pl->nnz[3];
     if (nnz == 0)                                                      // nothing stored: every row solves to zero
         return hipMemsetAsync(g, 0, (size_t)pl->n * ld * sizeof(float), st) == hipSuccess ? 0 : -2;
-    if (biasv) {                                                       // fold the fixed side's biases into the weights once
+    int bstride = 1;
+    if (biasv && wmf_bias_in_pad(f, ld)) {                             // the bias arrives with the gathered row (column f of V)
+        biasv = V + f;
+        bstride = ld;
+    } else if (biasv) {                                                // other widths: fold the biases into the weights once
         wmf_launch_bias_adjust(vals, indices, biasv, nnz, pl->w_eff, st);   // (w_eff: allocated by wmf_plan_create(bias = 1))
         vals = pl->w_eff;
         biasv = nullptr;
     }
     switch ((ld + 15) / 16) {
-#define C(N) case N: launch_low<N>(pl, V, biasv, indptr, indices, vals, ld, (f % 4 == 1 && ld == f + 3 && (ld / 4) % 4 == 1) ? 1 : 0, g, st); break;   /* the lanes' last slot holds that one piece only */
+#define C(N) case N: launch_low<N>(pl, V, biasv, bstride, indptr, indices, vals, ld, (f % 4 == 1 && ld == f + 3 && (ld / 4) % 4 == 1) ? 1 : 0, g, st); break;   /* the lanes' last slot holds that one piece only */
         C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)
 #undef C
         default: return -1;
@@ -739,7 +755,7 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
     {
         // rows bounced by the other kernels (negative weights / not positive definite); count is on the device
         if (general_ok) {
-            if (dispatch_general(pl->fallback_rows, 0, pl->fallback_count, 256, V, biasv, indptr, indices, vals, f, ld, g,
+            if (dispatch_general(pl->fallback_rows, 0, pl->fallback_count, 256, V, biasv, bstride, indptr, indices, vals, f, ld, g,
                                  fail_count, st)) return -1;
         } else {
             if (wmf_launch_wide_lu(pl->fallback_rows, pl->fallback_count, V, biasv, indptr, indices, vals, f, ld, g, fail_count,
