@@ -191,24 +191,34 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu):
     gamma = 0.1
     seed = SEEDS[cfg_name]
 
-    # ---- synthetic workload, generated on the GPU (identical on every rank) -----------------
+    # ---- synthetic workload, generated on the GPU: every rank makes only ITS block of user rows ---------------------
+    # The matrix is a fixed sequence of user blocks, each with its own random stream, so it is the same matrix whatever the
+    # number of ranks: 8 blocks of n_users / 8 rows (strong scaling; one rank generates 8 / N of them), or one block of
+    # the configuration's users per rank (weak scaling).  The engine then deals the rows of both sides by cost and moves
+    # every stored entry to the owners of its user and of its item (AlsEngine.set_interactions_distributed).
     t0 = time.perf_counter()
-    blocks = world if scaling == "weak" else 1
-    parts = [synth.make_counts(n_users_1, n_items, dbar, seed, device=dev, zipf_a=args.zipf, first_user=b * n_users_1)
-             for b in range(blocks)]
+    nb = world if (scaling == "weak" or 8 % world) else 8
+    per_block = n_users // nb
+    my_blocks = range(rank * nb // world, (rank + 1) * nb // world)
+    parts = [synth.make_counts(per_block if b < nb - 1 else n_users - per_block * (nb - 1), n_items, dbar, seed, device=dev,
+                               zipf_a=args.zipf, first_user=b * per_block) for b in my_blocks]
+    first_user = my_blocks[0] * per_block
     ptrs, offset = [parts[0][0][:1]], 0
     for ip_b, _, _ in parts:
         ptrs.append(ip_b[1:] + offset)
         offset += int(ip_b[-1])
-    indptr = torch.cat(ptrs)
+    indptr = torch.cat(ptrs)                        # this rank's user rows [first_user, first_user + len(indptr) - 1)
     indices = torch.cat([p[1] for p in parts])
     counts = torch.cat([p[2] for p in parts])
     del parts, ptrs
-    nnz = int(indices.numel())
+    nnz_t = torch.tensor([indices.numel()], dtype=torch.int64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(nnz_t)
+    nnz = int(nnz_t.item())
     eng = AlsEngine(n_users, n_items, k, bias, gamma, device=dev, chunks=args.chunks or None)
     values = counts.clone()
     eng.K.confidence_transform(values, 10.0, 1.0, 0)
-    eng.set_interactions(indptr, indices, values)
+    eng.set_interactions_distributed(first_user, indptr, indices, values, balance=True)
     from recmodel_amd import WMF                    # the package's own constructor draws the initial item factors
     eng.set_factors("items", WMF(num_items=n_items, num_users=1, dim=k, gamma=gamma, weighted=True, bias=bias).items)
     torch.cuda.synchronize()
@@ -248,7 +258,7 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu):
         elapsed = float(tmax.item())
 
     # ---- eval pass (not part of the timed step; reported separately) ------------------------
-    shard = eng.make_eval_shard(indptr, indices, counts)
+    shard = eng.make_eval_shard_distributed(first_user, indptr, indices, counts)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     sq, ab, cnt = eng.eval_sums(shard)
@@ -312,7 +322,8 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu):
         "config": {"workload": f"{cfg_name}: WMF k={k}{'+bias' if bias else ''}, {n_users}x{n_items} CSR, "
                                f"{nnz} nnz, alpha-log confidence, gamma={gamma}, zipf_a={args.zipf}",
                    "n_users": n_users, "n_items": n_items, "nnz": nnz, "k": k, "bias": bias,
-                   "sharding": f"users+items round-robin over {world} GPU(s); exchange users: "
+                   "sharding": f"users+items dealt by cost (nnz f^2 + f^3) over {world} GPU(s), every rank loads 1/{world} of the user "
+                               f"rows; exchange users: "
                                f"{'reduce-scatter of partial systems' if eng.reduce['users'] else 'all-gather'} in "
                                f"{len(eng.chunk_bounds['users'])} chunk(s), items: "
                                f"{'reduce-scatter of partial systems' if eng.reduce['items'] else 'all-gather'} in "
@@ -383,9 +394,7 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     lib = _lib.load()
 
-    scaling = args.scaling if args.scaling != "auto" else "strong"
-    if world == 1:
-        scaling = "weak"                       # one GPU: the per-GPU work is the whole workload either way
+    scaling = args.scaling if args.scaling != "auto" else "strong"     # (one GPU: the first point of the same series)
     main_res = run_workload(args.config, args, world, rank, dev, lib, scaling,
                             with_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
     also_name = args.also
@@ -401,7 +410,7 @@ def main():
         "metric": "ALS user+item row-updates/sec", "value": main_res.pop("value"),
         "unit": "row-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": main_res.pop("ms_per_step"), "higher_is_better": True,
-        "scaling": "weak" if world == 1 else scaling,
+        "scaling": scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "precision_note": "float32 storage, float32 accumulation everywhere; Gramian fp64 across waves; where a kernel is "
                           "MFMA-bound its products are three-way bf16 splits of the float32 operands (six bf16 MFMAs per tile, "

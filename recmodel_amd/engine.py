@@ -172,13 +172,101 @@ REDUCE_GAIN = 0.8               # reduce mode when its bytes per link are below 
 PIPE_MIN_ENTRIES = 48           # pipelined gather mode only when a row has at least this many entries per arriving chunk
 
 
-def gathered_positions(ids, world, rows_per_rank, chunk_len):
-    """Row of id ``ids`` in a chunk-major gathered matrix (module docstring).  Works on ints and tensors."""
-    j = ids // world
+class Sharding:
+    """Which rank owns an id of one side, and at which local row.  ``owner`` / ``local`` are None for the closed-form
+    round-robin deal (id i on rank i % W at local row i // W) or device tensors [n] for an explicit assignment
+    (``balanced_assignment``)."""
+
+    def __init__(self, n, world, rank, owner=None, local=None, counts=None):
+        self.n, self.world, self.rank = int(n), int(world), int(rank)
+        self.owner, self.local = owner, local
+        if owner is None:
+            self.counts = [len(range(r, self.n, self.world)) for r in range(self.world)]
+        else:
+            self.counts = [int(c) for c in counts]
+        self.n_local = self.counts[self.rank]
+        self.rpr = max(1, max(self.counts)) if self.n else 1          # rows per rank, padded to the largest block
+
+    def owner_of(self, ids):
+        return ids % self.world if self.owner is None else self.owner[ids].to(torch.int64)
+
+    def local_of(self, ids):
+        return ids // self.world if self.owner is None else self.local[ids].to(torch.int64)
+
+    def my_ids(self, device):
+        """ids of this rank's rows in local-row order."""
+        if self.owner is None:
+            return torch.arange(self.rank, self.n, self.world, device=device)
+        mine = torch.nonzero(self.owner.to(device) == self.rank).flatten()
+        return mine[torch.argsort(self.local.to(device)[mine])]
+
+
+def balanced_assignment(cost, world, heavy_per_rank=64):
+    """Deal rows over ``world`` ranks so that the summed cost per rank is equal -- SURVEY.md 8(e): rows cost
+    a * nnz * f^2 + b * f^3, and with power-law degrees equal row COUNTS are far from equal work.  Deterministic (every
+    rank computes the same deal from the same cost vector):
+      1. the heaviest rows (64 per rank) go, in descending cost, to the rank with the least cost so far (LPT);
+      2. of the remaining rows, taken in descending cost, each rank first receives a run that lifts it to the level of the
+         fullest rank, and the rest is dealt in serpentine order (0 .. W-1, W-1 .. 0), which keeps both the cost and the
+         row count of the ranks equal -- equal blocks are what all_gather_into_tensor moves without padding.
+    Returns (owner int32 [n], local int32 [n], counts [world]); local rows follow the ids within a rank."""
+    n = cost.numel()
+    dev = cost.device
+    c = cost.to(torch.float64)
+    order = torch.argsort(c, descending=True, stable=True)
+    cs = c[order]
+    owner_sorted = torch.empty(n, dtype=torch.int64, device=dev)
+    k = min(n, heavy_per_rank * world)
+    load = [0.0] * world
+    head = cs[:k].cpu().tolist()
+    head_owner = []
+    for v in head:                                           # LPT on the host: k is a few hundred
+        r = min(range(world), key=lambda i: (load[i], i))
+        load[r] += v
+        head_owner.append(r)
+    owner_sorted[:k] = torch.tensor(head_owner, dtype=torch.int64, device=dev)
+    if n > k:
+        tail = cs[k:]
+        cum = torch.cumsum(tail, 0)
+        need = [max(load) - x for x in load]                 # cost that lifts a rank to the fullest one
+        bounds, acc_need = [0], 0.0
+        for r in range(world):
+            acc_need += need[r]
+            bounds.append(int(torch.searchsorted(cum, torch.tensor(acc_need, dtype=torch.float64, device=dev), right=True)))
+        bounds = [min(b, n - k) for b in bounds]
+        t_owner = torch.empty(n - k, dtype=torch.int64, device=dev)
+        for r in range(world):
+            t_owner[bounds[r]: bounds[r + 1]] = r
+        rest = n - k - bounds[-1]
+        if rest > 0:
+            i = torch.arange(rest, device=dev)
+            lap, pos = i // world, i % world
+            t_owner[bounds[-1]:] = torch.where(lap % 2 == 0, pos, world - 1 - pos)
+        owner_sorted[k:] = t_owner
+    owner = torch.empty(n, dtype=torch.int64, device=dev)
+    owner[order] = owner_sorted
+    counts = torch.bincount(owner, minlength=world)
+    by_rank = torch.argsort(owner, stable=True)              # ids grouped by rank, ascending id inside a rank
+    start = torch.cumsum(counts, 0) - counts
+    local = torch.empty(n, dtype=torch.int64, device=dev)
+    local[by_rank] = torch.arange(n, device=dev) - start[owner[by_rank]]
+    return owner.to(torch.int32), local.to(torch.int32), counts.cpu().tolist()
+
+
+def row_cost(degrees, f):
+    """Work of one row update, SURVEY.md 8(e): nnz f^2 (accumulating its system) + f^3 (eliminating it)."""
+    return degrees.to(torch.float64) * float(f * f) + float(f) ** 3
+
+
+def gathered_positions(ids, world, rows_per_rank, chunk_len, owner=None, local=None):
+    """Row of id ``ids`` in a chunk-major gathered matrix (module docstring).  Works on ints and tensors; ``owner`` /
+    ``local`` give the rank and local row of every id (default: the round-robin deal)."""
+    j = ids // world if local is None else local
+    r = ids % world if owner is None else owner
     s_c = (j // chunk_len) * chunk_len
     rest = rows_per_rank - s_c
     len_c = torch.clamp(rest, max=chunk_len) if torch.is_tensor(rest) else min(chunk_len, rest)
-    return world * s_c + (ids % world) * len_c + (j - s_c)
+    return world * s_c + r * len_c + (j - s_c)
 
 
 class AlsEngine:
@@ -207,25 +295,35 @@ class AlsEngine:
         self.dim, self.bias, self.gamma = int(dim), bool(bias), float(gamma)
         self.f = self.dim + 1 if self.bias else self.dim
         self.ld = self.K.ld_for(self.f)
+        self.pr = self.K.partial_row_floats(self.f) if hasattr(self.K, "partial_row_floats") else 0
+        self._reduce_arg, self.pipe_mode, self._chunks_arg = reduce_mode, pipe_mode, chunks
+        self.csr = {}          # "users": shard with local user rows, "items": shard with local item rows
+        self.csr_chunks = {}   # the same rows as one Csr (own row plan) per chunk
+        self._configure({s: Sharding(self.n[s], self.world, self.rank) for s in self.n})
+
+    def _configure(self, shard):
+        """Everything that follows from who owns which row: block sizes, exchange mode per side, chunking, buffers.
+        Called with the round-robin deal by the constructor and again by set_interactions*(balance=True) once the
+        degrees are known (factors set before that are dropped: load them after the interactions)."""
         W = self.world
-        self.rpr = {s: (self.n[s] + W - 1) // W for s in self.n}            # rows per rank (padded)
-        self.n_local = {s: len(range(self.rank, self.n[s], W)) for s in self.n}
+        self.shard = shard
+        self.rpr = {s: shard[s].rpr for s in self.n}                          # rows per rank (padded to the largest block)
+        self.n_local = {s: shard[s].n_local for s in self.n}
+        pr, chunks = self.pr, self._chunks_arg
         # exchange mode per updated side (module docstring): "reduce" = accumulate everywhere + reduce-scatter, else gather
-        pr = self.K.partial_row_floats(self.f) if hasattr(self.K, "partial_row_floats") else 0
-        forced = os.environ.get("WMF_REDUCE") if reduce_mode is None else ("1" if reduce_mode else "0")
+        forced = os.environ.get("WMF_REDUCE") if self._reduce_arg is None else ("1" if self._reduce_arg else "0")
         self.reduce = {}
         for s in self.n:
             o = "items" if s == "users" else "users"
             gain = W > 1 and pr > 0 and self.rpr[s] * pr < REDUCE_GAIN * self.rpr[o] * self.ld
-            # a summed system that is not positive definite cannot be handed to the pivoted fallback (no CSR at the
-            # owner), and only bias-adjusted weights can go negative: with biases the mode has to be asked for
-            self.reduce[s] = self.exchange and pr > 0 and (forced == "1" or (forced is None and gain and not self.bias))
+            # A summed system that is not positive definite cannot be handed to the pivoted kernel by its owner (no CSR
+            # there); only bias-adjusted weights can go negative.  Bias models use the mode all the same: a half step that
+            # counted such a row is done again through the gather path (_redo_through_gather).
+            self.reduce[s] = self.exchange and pr > 0 and (forced == "1" or (forced is None and gain))
         if self.reduce["users"] and self.reduce["items"]:
             # both at once would leave nobody holding a whole side; keep the one that saves more
             keep = "items" if self.rpr["items"] <= self.rpr["users"] else "users"
             self.reduce = {s: s == keep for s in self.n}
-        self.pr = pr
-        self.pipe_mode = pipe_mode
         auto_chunks = chunks is None and "WMF_CHUNKS" not in os.environ
         if chunks is None:
             chunks = int(os.environ.get("WMF_CHUNKS", "4")) if self.exchange else 1
@@ -269,13 +367,15 @@ class AlsEngine:
         self.partial_mine = {s: (torch.empty(self.rpr[s], pr, dtype=f32, device=dev) if self.reduce[s] else None) for s in self.n}
         self.scratch_rows = torch.zeros(max(self.rpr.values()), dtype=torch.int32, device=dev)
         self._stale = {s: False for s in self.n}                              # X[s] not gathered since the last update
-        self.csr = {}          # "users": shard with local user rows, "items": shard with local item rows
-        self.csr_chunks = {}   # the same rows as one Csr (own row plan) per chunk
+        self.csr, self.csr_chunks = {}, {}
         self.has_factors = {"users": False, "items": False}
 
     # ---------------------------------------------------------------- id <-> position maps
     def positions(self, side, ids):
-        return gathered_positions(ids, self.world, self.rpr[side], self.chunk_len[side])
+        sh = self.shard[side]
+        if sh.owner is None:
+            return gathered_positions(ids, self.world, self.rpr[side], self.chunk_len[side])
+        return gathered_positions(ids, self.world, self.rpr[side], self.chunk_len[side], sh.owner_of(ids), sh.local_of(ids))
 
     def _other(self, side):
         return "items" if side == "users" else "users"
@@ -295,10 +395,11 @@ class AlsEngine:
                 raise IndexError(f"{what}: column index {hi if hi >= self.n['items'] else lo} is out of bounds for "
                                  f"num_items = {self.n['items']}")
 
-    def set_interactions(self, indptr, indices, values):
-        """Full user-major confidence matrix (device tensors, CSR as stored).  Builds this rank's
-        user-row shard and item-row shard (the transpose is taken here, on the device;
-        wmf_model.py:128 ``count_mat.T.tocsr()``)."""
+    def set_interactions(self, indptr, indices, values, balance=False):
+        """Full user-major confidence matrix (device tensors, CSR as stored), the same on every rank.  Builds this
+        rank's user-row shard and item-row shard (the transpose is taken here, on the device; wmf_model.py:128
+        ``count_mat.T.tocsr()``).  balance=True deals the rows of both sides by cost (balanced_assignment) instead of
+        round-robin; factors loaded before are dropped then."""
         dev = self.device
         indptr = indptr.to(dev, torch.int64)
         cols = indices.to(dev, torch.int64)
@@ -306,8 +407,97 @@ class AlsEngine:
         self._check_csr(indptr, cols, "count_mat")
         counts = indptr[1:] - indptr[:-1]
         rows = torch.repeat_interleave(torch.arange(self.n["users"], device=dev), counts)
+        if balance and self.world > 1:
+            self._balance(counts, torch.bincount(cols, minlength=self.n["items"]))
+        mine = {}
         for side, (r_, c_) in (("users", (rows, cols)), ("items", (cols, rows))):
-            full = self._shard(side, r_, c_, vals)
+            if self.world > 1:
+                m = self.shard[side].owner_of(r_) == self.rank
+                mine[side] = (r_[m], c_[m], vals[m])
+            else:
+                mine[side] = (r_, c_, vals)
+        self._build_shards(mine)
+
+    def set_interactions_distributed(self, first_user, indptr, indices, values, balance=True):
+        """The same from a matrix that is itself distributed: this rank holds the user rows
+        [first_user, first_user + len(indptr) - 1) of the user-major matrix and nothing else (a partition of a file, a
+        generator's block).  Every stored entry travels once to the owner of its user and once to the owner of its item
+        (all_to_all over the ranks); no rank ever sees the whole matrix.  The row degrees -- one number per row -- are
+        shared so that every rank computes the same cost-balanced deal."""
+        dev = self.device
+        indptr = indptr.to(dev, torch.int64)
+        cols = indices.to(dev, torch.int64)
+        vals = values.to(dev, torch.float32)
+        n_rows = indptr.numel() - 1
+        if int(indptr[-1]) != cols.numel() or (n_rows > 0 and bool((indptr[1:] < indptr[:-1]).any())):
+            raise ValueError("count_mat block: indptr is not a monotone row pointer over the stored entries")
+        if first_user < 0 or first_user + n_rows > self.n["users"]:
+            raise ValueError(f"count_mat block: user rows [{first_user}, {first_user + n_rows}) outside num_users = {self.n['users']}")
+        if cols.numel() and (int(cols.min()) < 0 or int(cols.max()) >= self.n["items"]):
+            raise IndexError(f"count_mat block: a column index is out of bounds for num_items = {self.n['items']}")
+        counts = indptr[1:] - indptr[:-1]
+        rows = first_user + torch.repeat_interleave(torch.arange(n_rows, device=dev), counts)
+        if balance and self.world > 1:
+            deg_u = torch.zeros(self.n["users"], dtype=torch.int64, device=dev)
+            deg_u[first_user: first_user + n_rows] = counts
+            deg_i = torch.bincount(cols, minlength=self.n["items"])
+            if self.exchange:
+                torch.distributed.all_reduce(deg_u, group=self.group)
+                torch.distributed.all_reduce(deg_i, group=self.group)
+            self._balance(deg_u, deg_i)
+        mine = {}
+        for side, (r_, c_) in (("users", (rows, cols)), ("items", (cols, rows))):
+            dest = self.shard[side].owner_of(r_)
+            mine[side] = self._exchange(dest, (r_, c_, vals)) if self.world > 1 else (r_, c_, vals)
+        self._build_shards(mine)
+
+    def _balance(self, deg_users, deg_items):
+        shard = {}
+        for side, deg in (("users", deg_users), ("items", deg_items)):
+            owner, local, counts = balanced_assignment(row_cost(deg, self.f), self.world)
+            shard[side] = Sharding(self.n[side], self.world, self.rank, owner.to(self.device), local.to(self.device), counts)
+        self._configure(shard)
+
+    def _exchange(self, dest, tensors):
+        """Send every entry to rank dest[entry]; returns what this rank receives (same tensor layout).  RCCL: one
+        all_to_all_single per tensor with the counts exchanged first; gloo (CPU rehearsal) has no all_to_all: every rank
+        gathers the padded buffers and keeps its part."""
+        W = self.world
+        order = torch.argsort(dest, stable=True)
+        send_counts = torch.bincount(dest, minlength=W)
+        backend = torch.distributed.get_backend(self.group)
+        if backend == "nccl":
+            recv_counts = torch.empty_like(send_counts)
+            torch.distributed.all_to_all_single(recv_counts, send_counts, group=self.group)
+            sc, rc = send_counts.tolist(), recv_counts.tolist()
+            out = []
+            for t in tensors:
+                buf = torch.empty(sum(rc), dtype=t.dtype, device=t.device)
+                torch.distributed.all_to_all_single(buf, t[order].contiguous(), rc, sc, group=self.group)
+                out.append(buf)
+            return tuple(out)
+        counts_all = [torch.empty_like(send_counts) for _ in range(W)]
+        torch.distributed.all_gather(counts_all, send_counts, group=self.group)
+        cap = int(torch.stack(counts_all).sum(1).max())
+        out = []
+        for t in tensors:
+            pad = torch.zeros(cap, dtype=t.dtype, device=t.device)
+            pad[: t.numel()] = t[order]
+            gathered = [torch.empty_like(pad) for _ in range(W)]
+            torch.distributed.all_gather(gathered, pad, group=self.group)
+            parts = []
+            for src in range(W):
+                c = counts_all[src]
+                lo = int(c[: self.rank].sum())
+                parts.append(gathered[src][lo: lo + int(c[self.rank])])
+            out.append(torch.cat(parts))
+        return tuple(out)
+
+    def _build_shards(self, mine):
+        """mine[side] = (row ids, column ids, values) of the entries whose ``side`` row this rank owns."""
+        for side in ("users", "items"):
+            r_, c_, v_ = mine[side]
+            full = self._shard(side, r_, c_, v_)
             self.csr[side] = full
             bounds = self.chunk_bounds[side]
             if len(bounds) == 1:
@@ -318,10 +508,9 @@ class AlsEngine:
                     Csr(self.K, full.indptr[lo: lo + ln + 1] - edges[c], full.indices[edges[c]: edges[c + 1]],
                         full.values[edges[c]: edges[c + 1]], full.n_cols, self.f, self.bias)
                     for c, (lo, ln) in enumerate(bounds)]
-
-        for side, (r_, c_) in (("users", (rows, cols)), ("items", (cols, rows))):
+        for side in ("users", "items"):
             if self.reduce[side]:
-                self.csr_red[side] = self._shard_reduce(side, r_, c_, vals)
+                self.csr_red[side] = self._shard_reduce(side)
             else:
                 self._setup_pipe(side)
 
@@ -333,7 +522,7 @@ class AlsEngine:
         forced = os.environ.get("WMF_PIPE") if self.pipe_mode is None else ("1" if self.pipe_mode else "0")
         heavy = full.nnz >= PIPE_MIN_ENTRIES * max(1, self.n_local[side]) * len(bounds)
         self.pipe[side] = (self.exchange and len(bounds) > 1 and self.pr > 0 and not self.reduce[fixed]
-                           and (forced == "1" or (forced is None and heavy and not self.bias)))
+                           and (forced == "1" or (forced is None and heavy)))
         if not self.pipe[side]:
             return
         W, n = self.world, self.rpr[side]
@@ -351,31 +540,29 @@ class AlsEngine:
         self.csr_pipe[side] = subs
         self.partial_pipe[side] = torch.empty(n * len(bounds), self.pr, dtype=torch.float32, device=self.device)
 
-    def _shard_reduce(self, side, rows, cols, vals):
-        """Reduce mode: every row of ``side`` (at its gathered position) x this rank's rows of the other side
-        (local indices).  Returns (indptr, degrees int32, indices int32, values, w_eff workspace)."""
-        W, r = self.world, self.rank
-        mine = (cols % W) == r
-        rows, cols, vals = rows[mine], cols[mine], vals[mine]
-        indptr, idx, v = coo_to_csr(self.positions(side, rows), cols // W, vals, W * self.rpr[side])
+    def _shard_reduce(self, side):
+        """Reduce mode: every row of ``side`` (at its gathered position) x this rank's rows of the other side (local
+        rows) -- the transpose of this rank's own shard of the other side, whose column indices ARE the gathered positions
+        of ``side``.  Returns (indptr, degrees int32, indices int32, values, w_eff workspace)."""
+        o = self.csr[self._other(side)]
+        local_rows = torch.repeat_interleave(torch.arange(o.n_rows, device=self.device), o.indptr[1:] - o.indptr[:-1])
+        indptr, idx, v = coo_to_csr(o.indices.to(torch.int64), local_rows, o.values, self.world * self.rpr[side])
         deg = (indptr[1:] - indptr[:-1]).to(torch.int32).contiguous()
         w_eff = torch.empty_like(v) if self.bias else None
         return indptr.contiguous(), deg, idx.contiguous(), v.contiguous(), w_eff
 
     def _shard(self, side, rows, cols, vals):
-        W, r = self.world, self.rank
+        """CSR of this rank's rows of ``side`` (all of them its own already): local row x gathered position of the column."""
         other = self._other(side)
-        if W > 1:
-            mine = (rows % W) == r
-            rows, cols, vals = rows[mine], cols[mine], vals[mine]
-        local = rows // W
+        local = self.shard[side].local_of(rows)
         indptr, idx, v = coo_to_csr(local, self.positions(other, cols), vals, self.rpr[side])
-        return Csr(self.K, indptr, idx, v, W * self.rpr[other], self.f, self.bias)
+        return Csr(self.K, indptr, idx, v, self.world * self.rpr[other], self.f, self.bias)
 
     def set_factors(self, side, full):
         """Load a full host/device [n, f] factor matrix (reference layout) into this rank's block."""
         full = torch.as_tensor(full, dtype=torch.float32)
-        mine = full[self.rank::self.world].to(self.device)
+        sh = self.shard[side]
+        mine = (full[self.rank::self.world] if sh.owner is None else full[sh.my_ids(full.device)]).to(self.device)
         blk = self.factors[side]
         blk.zero_()
         blk[: mine.shape[0], : self.f] = mine
@@ -493,6 +680,8 @@ class AlsEngine:
             K.accumulate_rows(V, bvec if self.bias else None, ptr, deg, idx, val, n, idx.numel(), self.f, self.ld,
                               self.partial_pipe[side], w_eff, slot_stride=C, slot_offset=c)
         K.eliminate_rows(self.partial_pipe[side], n, self.f, self.ld, self.g[side], self.fail, self.scratch_rows, slots_per_row=C)
+        if self._summed_system_failed():
+            return self._redo_through_gather(side)
         K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, False, self.factors[side], None)
         self.has_factors[side] = True
         for c in range(len(self.chunk_bounds[side])):
@@ -525,10 +714,39 @@ class AlsEngine:
             if w is not None:
                 w.wait()
         K.eliminate_rows(self.partial_mine[side], self.rpr[side], self.f, self.ld, self.g[side], self.fail, self.scratch_rows)
+        if self._summed_system_failed():
+            return self._redo_through_gather(side)
         K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, False, self.factors[side], None)
         self.has_factors[side] = True
         for c in range(len(self.chunk_bounds[side])):
             self._publish(side, c)
+
+    def _summed_system_failed(self):
+        """Bias models in reduce / pipelined mode: did any rank meet a row whose summed system is not positive definite
+        (negative bias-adjusted weights)?  One small all-reduce and one host sync per half step -- the price of letting
+        bias models use the two modes; models without biases never ask (their systems are positive definite by
+        construction)."""
+        if not self.bias:
+            return False
+        flag = self.fail[:1].clone()
+        if self.exchange:
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=self.group)
+        if int(flag.item()) == 0:
+            return False
+        self.fail.zero_()                            # those rows are solved again below, by kernels that can pivot
+        return True
+
+    def _redo_through_gather(self, side):
+        """The half step again through the all-gather path: its row kernels see the rows' own entries and hand a row with
+        negative weights to the pivoted kernel (the reference's np.linalg.solve, wmf_model.py:350).  The Gramian and its
+        factor are still those of this half step; the fixed side is gathered (it may not have been: reduce mode) and
+        whitened as a whole."""
+        K, W = self.K, self.world
+        fixed = self._other(side)
+        self._ensure_gathered(fixed)
+        K.row_transform(self.X[fixed], W * self.rpr[fixed], self.f, self.ld, self.W_white, self.bias, self.V[fixed],
+                        self.bias_vec[fixed] if self.bias else None)
+        self.update(side)
 
     def _reduce_scatter(self, out, inp):
         """out = this rank's slice of the sum over ranks of inp (rank-major blocks).  Backends without a
@@ -579,7 +797,24 @@ class AlsEngine:
         self._check_csr(indptr, cols, "utility_mat / eval_mat")
         counts = indptr[1:] - indptr[:-1]
         rows = torch.repeat_interleave(torch.arange(self.n["users"], device=dev), counts)
-        return self._shard("users", rows, cols, values.to(dev, torch.float32))
+        vals = values.to(dev, torch.float32)
+        if self.world > 1:
+            m = self.shard["users"].owner_of(rows) == self.rank
+            rows, cols, vals = rows[m], cols[m], vals[m]
+        return self._shard("users", rows, cols, vals)
+
+    def make_eval_shard_distributed(self, first_user, indptr, indices, values):
+        """make_eval_shard from this rank's block of user rows (set_interactions_distributed): every entry travels to the
+        owner of its user."""
+        dev = self.device
+        indptr = indptr.to(dev, torch.int64)
+        cols = indices.to(dev, torch.int64)
+        vals = values.to(dev, torch.float32)
+        counts = indptr[1:] - indptr[:-1]
+        rows = first_user + torch.repeat_interleave(torch.arange(indptr.numel() - 1, device=dev), counts)
+        if self.world > 1:
+            rows, cols, vals = self._exchange(self.shard["users"].owner_of(rows), (rows, cols, vals))
+        return self._shard("users", rows, cols, vals)
 
     def eval_sums(self, shard):
         """(sum of squared errors, sum of absolute errors, count) over the stored non-zero entries

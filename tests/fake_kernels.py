@@ -96,6 +96,11 @@ class NumpyKernels:
         out[:n] = 0
         for i in range(n):
             A = np.eye(f) + P[i, : f * f].reshape(f, f)
+            try:                                       # like the device kernel: no pivoting here, a system that is not
+                np.linalg.cholesky(A)                  # positive definite is counted and left for the caller
+            except np.linalg.LinAlgError:
+                fail.numpy()[0] += 1
+                continue
             out[i, :f] = np.linalg.solve(A, P[i, f * f:])
 
     def spmm_rows(self, V, indptr, indices, values, n, f, ld, g):

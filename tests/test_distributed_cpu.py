@@ -195,3 +195,132 @@ def test_numeric_failure_on_one_rank_raises_on_all(tmp_path):
     mp.spawn(_worker_singular, args=(2, _free_port(), out), nprocs=2, join=True)
     got = np.load(out)
     assert got[0] == 2.0 and got[1] == 0.0       # both ranks raised; the flag was reset
+
+
+def _worker_distributed_build(rank, world, port, bias, out_path, mode):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_kernels import NumpyKernels
+        from oracle import wmf_oracle as orc
+        from recmodel_amd import synth
+        from recmodel_amd.engine import AlsEngine, row_cost
+        n_users, n_items, dim = 211, 64, 5
+        indptr, indices, counts = synth.make_counts(n_users, n_items, 6, seed=13, zipf_a=1.1)
+        values = (10 * torch.log(1 + counts)).to(torch.float32)
+        # this rank's block of user rows: contiguous, unequal (the last rank gets the remainder)
+        per = n_users // world
+        lo = rank * per
+        hi = n_users if rank == world - 1 else lo + per
+        e0, e1 = int(indptr[lo]), int(indptr[hi])
+        kw = {"gather": {}, "reduce": {"reduce_mode": True}, "pipe": {"reduce_mode": False, "pipe_mode": True}}[mode]
+        eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cpu", kernels=NumpyKernels(), chunks=3, **kw)
+        eng.set_interactions_distributed(lo, indptr[lo: hi + 1] - e0, indices[e0:e1], values[e0:e1], balance=True)
+        # the deal is explicit and cost-balanced, and every stored entry landed on exactly one rank, in both orientations
+        assert eng.shard["users"].owner is not None and eng.shard["items"].owner is not None
+        for side in ("users", "items"):
+            t = torch.tensor([eng.csr[side].nnz], dtype=torch.int64)
+            dist.all_reduce(t)
+            assert int(t) == indices.numel()
+        deg_i = torch.bincount(indices, minlength=n_items)
+        cost = row_cost(deg_i, eng.f)
+        mine = torch.tensor([float(cost[eng.shard["items"].owner.to(torch.int64) == rank].sum())], dtype=torch.float64)
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        allc = torch.cat(allc)
+        assert float((allc.max() - allc.min()) / allc.mean()) < 0.2          # (64 rows over 2-3 ranks: coarse, but not 2x)
+        eng.set_factors("items", orc.init_items(n_items, dim, bias))
+        for _ in range(2):
+            eng.half_step("users")
+            eng.half_step("items")
+        eng.check_numerics()
+        shard = eng.make_eval_shard_distributed(lo, indptr[lo: hi + 1] - e0, indices[e0:e1], counts[e0:e1])
+        sq, ab, cnt = eng.eval_sums(shard)
+        users, items = eng.get_factors("users"), eng.get_factors("items")
+        if rank == 0:
+            np.savez(out_path, users=users, items=items, sums=np.array([sq, ab, cnt]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bias,mode", [(2, False, "gather"), (3, True, "gather"), (2, False, "reduce"), (3, False, "pipe"),
+                                             (2, True, "reduce")])
+def test_distributed_build_with_balanced_deal_matches_oracle(tmp_path, world, bias, mode):
+    """Every rank hands over only ITS block of user rows (set_interactions_distributed): degrees are shared, the rows of
+    both sides are dealt by cost (balanced_assignment, explicit owner / local-row maps instead of id % W), the entries
+    travel to their owners, and two ALS iterations equal the single-process oracle on the whole matrix -- in all three
+    exchange modes, with biases too."""
+    from oracle import wmf_oracle as orc
+    from recmodel_amd import synth
+    out = str(tmp_path / "out.npz")
+    mp.spawn(_worker_distributed_build, args=(world, _free_port(), bias, out, mode), nprocs=world, join=True)
+    got = np.load(out)
+    n_users, n_items, dim = 211, 64, 5
+    indptr, indices, counts = synth.make_counts(n_users, n_items, 6, seed=13, zipf_a=1.1)
+    raw = synth.to_scipy(indptr, indices, counts, (n_users, n_items))
+    C = raw.astype(np.float64)
+    C.data = 10 * np.log(1 + C.data)
+    CT = C.T.tocsr()
+    items = orc.init_items(n_items, dim, bias)
+    step = orc.recompute_factors_bias if bias else orc.recompute_factors
+    for _ in range(2):
+        users = step(items, C, 0.1)
+        items = step(users, CT, 0.1)
+    np.testing.assert_allclose(got["users"], users, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(got["items"], items, rtol=2e-4, atol=2e-5)
+    mse = orc.eval_prec(users, items, raw, bias)
+    assert abs(got["sums"][0] / got["sums"][2] - mse) <= 1e-4 * mse and got["sums"][2] == raw.nnz
+
+
+def _worker_negative_weights(rank, world, port, out_path, mode):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_kernels import NumpyKernels
+        from recmodel_amd import synth
+        from recmodel_amd.engine import AlsEngine
+        n_users, n_items, dim = 90, 40, 4
+        indptr, indices, counts = synth.make_counts(n_users, n_items, 5, seed=3)
+        kw = {"reduce": {"reduce_mode": True}, "pipe": {"reduce_mode": False, "pipe_mode": True}}[mode]
+        eng = AlsEngine(n_users, n_items, dim, True, 0.1, device="cpu", kernels=NumpyKernels(), chunks=2, **kw)
+        eng.set_interactions(indptr, indices, counts)                # raw counts 2 .. as weights
+        items0 = _negative_weight_items(n_items, dim)
+        eng.set_factors("items", items0)
+        eng.half_step("users")                                       # all-gather mode for the users here (reduce: items only)
+        eng.half_step("items")
+        eng.check_numerics()
+        users, items = eng.get_factors("users"), eng.get_factors("items")
+        if rank == 0:
+            np.savez(out_path, users=users, items=items)
+    finally:
+        dist.destroy_process_group()
+
+
+def _negative_weight_items(n_items, dim):
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((n_items, dim + 1)).astype(np.float32) * 0.3
+    y[:, 0] = 30.0                    # item biases far above every count: all bias-adjusted weights are negative
+    return y
+
+
+@pytest.mark.parametrize("mode", ["reduce", "pipe"])
+def test_bias_model_in_reduce_and_pipe_mode_survives_negative_weights(tmp_path, mode):
+    """A row whose summed partial system is not positive definite (bias-adjusted weights below zero) cannot be pivoted by
+    its owner in reduce / pipelined mode; the engine notices (one flag, max-reduced) and does that half step again through
+    the all-gather path, whose kernels pivot.  Result = the oracle's LU solve."""
+    from oracle import wmf_oracle as orc
+    from recmodel_amd import synth
+    out = str(tmp_path / "neg.npz")
+    mp.spawn(_worker_negative_weights, args=(2, _free_port(), out, mode), nprocs=2, join=True)
+    got = np.load(out)
+    n_users, n_items, dim = 90, 40, 4
+    indptr, indices, counts = synth.make_counts(n_users, n_items, 5, seed=3)
+    C = synth.to_scipy(indptr, indices, counts, (n_users, n_items)).astype(np.float64)
+    users = orc.recompute_factors_bias(_negative_weight_items(n_items, dim), C, 0.1)
+    items = orc.recompute_factors_bias(users, C.T.tocsr(), 0.1)
+    np.testing.assert_allclose(got["users"], users, rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(got["items"], items, rtol=5e-4, atol=5e-5)
