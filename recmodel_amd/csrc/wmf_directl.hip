@@ -74,15 +74,20 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // used three bf16 parts and six MFMAs (exact split, 9 instructions per value); measured on the CPU prototype
 // (tests/scale/proto_split.py, tests/scale/proto_f16.py) the accumulated tile and the solved row are as accurate as with f32
 // MFMAs either way: the tile's own f32 accumulation, not the 2^-22 of the operands, sets its error.
-// Scale DL_S = 64: whitened factors are small (|v| ~ 1 / sqrt(rows of the fixed side)), and an f16 below 6.1e-5 is a
-// denormal; the factor keeps the low parts of ordinary data normal.  Tiles, right-hand side and border then all carry
-// DL_S^2, which the elimination is told about (its identity is DL_S^2: wmf_dw_elim.h).  Robustness: an operand beyond the f16
-// range (|v sqrt(w)| >= 1024) becomes an infinity whose hi.hi and lo.hi products meet in the diagonal tile as inf - inf, and
-// a negative weight has no square root: either way a NaN reaches the pivot test and the row is bounced to the pivoted
-// kernel, like every system that is not positive definite.  A chunk = two ring slots = 32 entries; lane (r, q) takes
-// entries 8 q .. 8 q + 7 of the chunk (the K index of its MFMA operands).
+// Scale DL_S: operands can be scaled by a power of two before the split (tiles, right-hand side and border then all carry
+// DL_S^2, which the elimination is told about: wmf_dw_elim.h).  It is 1: whitened factors are small (|v| ~ 1 / sqrt(rows of
+// the fixed side)) and their low parts are f16 denormals, but what the row system I + V^T D V needs is ABSOLUTE accuracy
+// against its unit diagonal, and a denormal is exact to 3e-8 -- measured, DL_S = 1 and DL_S = 64 give the same rows
+// (tools/lab/diag_f16.py), and only at unit scale are the inverse pivot tiles of the elimination O(1), which their own
+// split needs.  Robustness: an operand beyond the f16 range (|v sqrt(w)| >= 65520) becomes an infinity whose hi.hi and lo.hi
+// products meet in the diagonal tile as inf - inf, and a negative weight has no square root: either way a NaN reaches the
+// pivot test and the row is bounced to the pivoted kernel, like every system that is not positive definite.  A chunk = two
+// ring slots = 32 entries; lane (r, q) takes entries 8 q .. 8 q + 7 of the chunk (the K index of its MFMA operands).
 #ifndef DL_S
-#define DL_S 64.f
+#define DL_S 1.f
+#endif
+#ifndef DL_F16T
+#define DL_F16T 1            // the elimination's tile products as split-f16 MFMAs too (wmf_dw_elim.h); 0: f32 MFMAs
 #endif
 #ifndef DL_LOMODE
 #define DL_LOMODE 0          // lab: 1 = no low parts, 2 = low parts negated
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
                 cacc *= S2; eacc *= S2;
             }
         }
-        dw_eliminate<NFB, BORDER, (DL_GJ_LDS != 0), true>(acc, racc, bacc, cacc, eacc, nullptr, nullptr, r, q, baddr, dbg, gb, tb, ok,
+        dw_eliminate<NFB, BORDER, (DL_GJ_LDS != 0), true, (X6 && DL_F16T != 0)>(acc, racc, bacc, cacc, eacc, nullptr, nullptr, r, q, baddr, dbg, gb, tb, ok,
                                                           X6 ? DL_S * DL_S : 1.f);
         if (!ok) {
             if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;

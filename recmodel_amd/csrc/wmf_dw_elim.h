@@ -24,7 +24,29 @@ __device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for
 // WREG: w_p (and w^b_p) stay in registers instead of the two LDS vectors -- after the DPP row sums every lane (., q) holds
 // w_p[4q + reg] already, which is all the backward pass reads (used by the LDS-DMA kernel, which keeps LDS accesses that the
 // compiler can see out of the kernel).
-template <int NFB, bool BORDER, bool GJ_LDS, bool WREG = false>
+// F16T: the tile products of the elimination (W_pj = X B_pj, B_ij -= B_pi^T W_pj: 448 f32 MFMAs at NFB = 8, 14 k cycles of
+// the SIMD's one f32 pipe) as split-f16 MFMAs.  A 16 x 16 x 16 product uses half of a v_mfma_f32_16x16x32_f16's K = 32,
+// so the other half carries the low parts: every tile is split once into f16 high and low parts, h + l (22 significand
+// bits, 2^-23 relative), a lane's four values k = 4q + e give the operand { h_0..h_3, l_0..l_3 } (natural), and
+//     A . B = mfma({ah, ah}, {bh, bl}) + mfma({al, al}, {bh, bl}) = (ah + al)(bh + bl)
+// with no cross-lane movement at all (slot (q, jj) means k = 4q + (jj & 3) on every lane).  Two 16-cycle MFMAs that leave
+// half their cycles to the VALU replace four 32-cycle ones; the splits cost 12 VALU instructions per tile of the pivot row.
+typedef _Float16 dw_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ dw_f16x8 dw_split_natural(const f32x4 v) {
+    dw_f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma clang fp contract(off)
+        const _Float16 h = (_Float16)v[e];
+        o[e] = h;
+        o[4 + e] = (_Float16)(v[e] - (float)h);
+    }
+    return o;
+}
+__device__ __forceinline__ dw_f16x8 dw_dup_hi(const dw_f16x8 n) { return __builtin_shufflevector(n, n, 0, 1, 2, 3, 0, 1, 2, 3); }
+__device__ __forceinline__ dw_f16x8 dw_dup_lo(const dw_f16x8 n) { return __builtin_shufflevector(n, n, 4, 5, 6, 7, 4, 5, 6, 7); }
+
+template <int NFB, bool BORDER, bool GJ_LDS, bool WREG = false, bool F16T = false>
 __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], float (&racc)[NFB], float (&bacc)[BORDER ? NFB : 1],
                                              float& cacc, float& eacc, float* Wv, float* Wb, int r,
                                              int q, const int (&baddr)[4], int dbg, float (&gb)[NFB], float& tb, bool& ok,
@@ -88,35 +110,72 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
                 cacc -= b0 * wb0 + b1 * wb1 + b2 * wb2 + b3 * wb3;
                 eacc -= b0 * wv0 + b1 * wv1 + b2 * wv2 + b3 * wv3;
             }
-            // Row p: W_pj = X B_pj replaces the tile, the original goes to `orig` for the trailing update.  Both operands
-            // of that update are elements THIS lane already holds: instruction e of  B_ij -= B_pi^T W_pj  wants
-            // A[m = r][k = q] = B_pi[4q + e][r] and B[k = q][n = r] = W_pj[4q + e][r], i.e. register e of the two tiles in
-            // accumulator layout -- no LDS panel, no exchange.
-            f32x4 orig[NFB];
+            if constexpr (F16T) {
+                // Row p in split f16 (header comment): W'_pj = -X B_pj replaces the tile (the sign makes the trailing update
+                // an accumulation; the backward pass subtracts instead), y_j and b_j get their updates from the f32 tile
+                // before it is overwritten.
+                f32x4 nX;
 #pragma unroll
-            for (int j = p + 1; j < NFB; ++j) {
-                const int t = tile_w<NFB>(p, j);
-                orig[j] = acc[t];
-                f32x4 n = f32x4{0.f, 0.f, 0.f, 0.f};
-                n = WMF_MFMA16(X[0], acc[t][0], n); n = WMF_MFMA16(X[1], acc[t][1], n);
-                n = WMF_MFMA16(X[2], acc[t][2], n); n = WMF_MFMA16(X[3], acc[t][3], n);
-                acc[t] = n;                                  // W_pj stays in registers for the backward pass too
-            }
+                for (int e = 0; e < 4; ++e) nX[e] = -X[e];
+                const dw_f16x8 xn = dw_split_natural(nX), xh = dw_dup_hi(xn), xl = dw_dup_lo(xn);
+                dw_f16x8 nb[NFB], nw[NFB];
 #pragma unroll
-            for (int i = p + 1; i < NFB; ++i) {
-                float a[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a[e] = -orig[i][e];
-                // y_i[r] -= sum_rows B_pi[row][r] w_p[row]: this lane's rows are 4q + e, a[e] = -B_pi[4q + e][r]
-                racc[i] += a[0] * wv0 + a[1] * wv1 + a[2] * wv2 + a[3] * wv3;
-                if constexpr (BORDER) bacc[i] += a[0] * wb0 + a[1] * wb1 + a[2] * wb2 + a[3] * wb3;
-#pragma unroll
-                for (int j = i; j < NFB; ++j) {
-                    const int t = tile_w<NFB>(i, j), tw = tile_w<NFB>(p, j);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[t] = WMF_MFMA16(a[e], acc[tw][e], acc[t]);
+                for (int j = p + 1; j < NFB; ++j) {
+                    const int t = tile_w<NFB>(p, j);
+                    const f32x4 B = acc[t];
+                    racc[j] -= B[0] * wv0 + B[1] * wv1 + B[2] * wv2 + B[3] * wv3;        // y_j[r] -= sum_rows B_pj[row][r] w_p[row]
+                    if constexpr (BORDER) bacc[j] -= B[0] * wb0 + B[1] * wb1 + B[2] * wb2 + B[3] * wb3;
+                    nb[j] = dw_split_natural(B);
+                    f32x4 n = f32x4{0.f, 0.f, 0.f, 0.f};
+                    n = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, nb[j], n, 0, 0, 0);
+                    n = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, nb[j], n, 0, 0, 0);
+                    acc[t] = n;                                  // W'_pj = -W_pj stays in registers for the backward pass too
+                    nw[j] = dw_split_natural(n);
                 }
-                if (i == p + 1) Xnext = invert(p + 1);           // tile (p + 1, p + 1) is final: look ahead
+#pragma unroll
+                for (int i = p + 1; i < NFB; ++i) {
+                    const dw_f16x8 ah = dw_dup_hi(nb[i]), al = dw_dup_lo(nb[i]);
+#pragma unroll
+                    for (int j = i; j < NFB; ++j) {
+                        const int t = tile_w<NFB>(i, j);
+                        f32x4 c = acc[t];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, nw[j], c, 0, 0, 0);     // B_ij += B_pi^T W'_pj
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, nw[j], c, 0, 0, 0);
+                        acc[t] = c;
+                    }
+                    if (i == p + 1) Xnext = invert(p + 1);           // tile (p + 1, p + 1) is final: look ahead
+                }
+            } else {
+                // Row p: W_pj = X B_pj replaces the tile, the original goes to `orig` for the trailing update.  Both operands
+                // of that update are elements THIS lane already holds: instruction e of  B_ij -= B_pi^T W_pj  wants
+                // A[m = r][k = q] = B_pi[4q + e][r] and B[k = q][n = r] = W_pj[4q + e][r], i.e. register e of the two tiles in
+                // accumulator layout -- no LDS panel, no exchange.
+                f32x4 orig[NFB];
+    #pragma unroll
+                for (int j = p + 1; j < NFB; ++j) {
+                    const int t = tile_w<NFB>(p, j);
+                    orig[j] = acc[t];
+                    f32x4 n = f32x4{0.f, 0.f, 0.f, 0.f};
+                    n = WMF_MFMA16(X[0], acc[t][0], n); n = WMF_MFMA16(X[1], acc[t][1], n);
+                    n = WMF_MFMA16(X[2], acc[t][2], n); n = WMF_MFMA16(X[3], acc[t][3], n);
+                    acc[t] = n;                                  // W_pj stays in registers for the backward pass too
+                }
+    #pragma unroll
+                for (int i = p + 1; i < NFB; ++i) {
+                    float a[4];
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = -orig[i][e];
+                    // y_i[r] -= sum_rows B_pi[row][r] w_p[row]: this lane's rows are 4q + e, a[e] = -B_pi[4q + e][r]
+                    racc[i] += a[0] * wv0 + a[1] * wv1 + a[2] * wv2 + a[3] * wv3;
+                    if constexpr (BORDER) bacc[i] += a[0] * wb0 + a[1] * wb1 + a[2] * wb2 + a[3] * wb3;
+    #pragma unroll
+                    for (int j = i; j < NFB; ++j) {
+                        const int t = tile_w<NFB>(i, j), tw = tile_w<NFB>(p, j);
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[t] = WMF_MFMA16(a[e], acc[tw][e], acc[t]);
+                    }
+                    if (i == p + 1) Xnext = invert(p + 1);           // tile (p + 1, p + 1) is final: look ahead
+                }
             }
         }
     }
@@ -145,7 +204,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
             for (int j = p + 1; j < NFB; ++j) {
                 const int t = tile_w<NFB>(p, j);
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) s[reg] += acc[t][reg] * gb[j];
+                for (int reg = 0; reg < 4; ++reg) s[reg] += (F16T ? -acc[t][reg] : acc[t][reg]) * gb[j];      // (F16T: the tile holds -W_pj)
             }
             float gsel = 0.f;
 #pragma unroll
