@@ -217,7 +217,10 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, int bias, wmf_plan*
     for (int b = 0; b < WMF_NBINS; ++b) start[b + 1] = start[b] + p->count[b];
     int64_t fill[WMF_NBINS];
     for (int b = 0; b < WMF_NBINS; ++b) fill[b] = start[b];
-    // within the MFMA bin: ordinary rows first, rows with more than WMF_HEAVY_T entries last (split into segments)
+    // within the bin of rows with more than 32 entries (one wave per row for f <= 144; four waves per row -- the row-split
+    // kernel, f <= 257 -- beyond): ordinary rows first, rows with more than WMF_HEAVY_T entries last (split into segments)
+    const int hb = wmf_direct_supported(f) ? WMF_BIN_MFMA : WMF_BIN_GENERAL;
+    const bool can_split = wmf_direct_supported(f) || wmf_rowsplit_supported(f);
     std::vector<int32_t> heavy;
     // first bin: rows with at most 8 entries first (two of them share a wave), the others behind them
     for (int64_t r = 0; r < n; ++r) {
@@ -228,13 +231,13 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, int bias, wmf_plan*
         const int64_t d = indptr[r + 1] - indptr[r];
         const int b = bin_of(d, f);
         if (b == WMF_BIN_LOW16 && d <= 8) continue;
-        if (b == WMF_BIN_MFMA && d > WMF_HEAVY_T) { heavy.push_back((int32_t)r); continue; }
+        if (b == hb && can_split && d > WMF_HEAVY_T) { heavy.push_back((int32_t)r); continue; }
         order[(size_t)fill[b]++] = (int32_t)r;
     }
     std::vector<int64_t> seg_lo;
     std::vector<int32_t> seg_d, seg_first(1, 0);
     for (int32_t r : heavy) {
-        order[(size_t)fill[WMF_BIN_MFMA]++] = r;
+        order[(size_t)fill[hb]++] = r;
         const int64_t d = indptr[r + 1] - indptr[r];
         p->heavy_nnz += d;
         for (int64_t off = 0; off < d; off += WMF_SEG) {
@@ -259,10 +262,11 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, int bias, wmf_plan*
     if (e == hipSuccess && f > 144) e = hipMalloc((void**)&p->wide_ws, wmf_wide_lu_workspace_bytes(f));
     if (e == hipSuccess && p->heavy_count > 0) {
         const int64_t nfb = (f + 15) / 16, nt = nfb * (nfb + 1) / 2 + nfb;
+        const int64_t pfloats = wmf_direct_supported(f) ? nt * 256 : wmf_rowsplit_partial_floats(f);
         e = hipMalloc((void**)&p->seg_lo, seg_lo.size() * sizeof(int64_t));
         if (e == hipSuccess) e = hipMalloc((void**)&p->seg_d, seg_d.size() * sizeof(int32_t));
         if (e == hipSuccess) e = hipMalloc((void**)&p->seg_first, seg_first.size() * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&p->partial, (size_t)p->seg_total * nt * 256 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&p->partial, (size_t)p->seg_total * pfloats * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(p->seg_lo, seg_lo.data(), seg_lo.size() * sizeof(int64_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(p->seg_d, seg_d.data(), seg_d.size() * sizeof(int32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(p->seg_first, seg_first.data(), seg_first.size() * sizeof(int32_t), hipMemcpyHostToDevice);

@@ -230,8 +230,10 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
             continue;
         }
         if constexpr (MODE == 2) {                               // sum the segments of heavy row `it` in a fixed order
-            // seg_first == NULL: row `it` owns the slot_a consecutive slots it * slot_a ..
-            const int64_t sg0 = seg_first ? seg_first[it] : it * slot_a, sg1 = seg_first ? seg_first[it + 1] : sg0 + slot_a;
+            // seg_first == NULL: row `it` owns the slot_a consecutive slots it * slot_a ..; seg_first with slot_a == 0: the
+            // segments were already summed into the row's first slot (wmf_launch_combine_segments)
+            const int64_t sg0 = seg_first ? seg_first[it] : it * slot_a;
+            const int64_t sg1 = seg_first ? (slot_a == 0 ? sg0 + 1 : seg_first[it + 1]) : sg0 + slot_a;
             for (int64_t sgm = sg0; sgm < sg1; ++sgm) {
                 const float* in = partial + sgm * (int64_t)WMF_DW_PARTIAL(NFB, BORDER);
 #pragma unroll
@@ -312,9 +314,10 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
                    nseg, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg, pl->seg_lo,
                    pl->seg_d, pl->seg_first, pl->partial, 1, 0);
         const int64_t nh = pl->heavy_count;
+        wmf_launch_combine_segments(pl, WMF_DW_PARTIAL(NFB, BORDER), st);
         WMF_LAUNCH(nm2, (solve_directw_kernel<NFB, 2, BORDER>), dim3((unsigned)(nh < cap ? nh : cap)), dim3(64), 0, st,
                    rows + normal, nh, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
-                   pl->seg_lo, pl->seg_d, pl->seg_first, pl->partial, 1, 0);
+                   pl->seg_lo, pl->seg_d, pl->seg_first, pl->partial, 0, 0);
     }
 }
 

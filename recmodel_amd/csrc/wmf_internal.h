@@ -75,9 +75,11 @@ int wmf_launch_wide(const int32_t* rows, int64_t count, const float* V, const fl
                     const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
                     int32_t* fb_count, hipStream_t st);
 int wmf_rowsplit_supported(int f);
-int wmf_launch_rowsplit(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
-                        const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
-                        int32_t* fb_count, hipStream_t st);
+int wmf_launch_rowsplit(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
+                        const int32_t* indices, const float* vals, int f, int ld, float* g, hipStream_t st);
+int64_t wmf_rowsplit_partial_floats(int f);      // floats of one segment's partial system
+// partial systems of the segments of every split row summed, in segment order, into the row's first slot (wmf_solve.hip)
+void wmf_launch_combine_segments(const wmf_plan* pl, int64_t partial_floats, hipStream_t st);
 size_t wmf_wide_lu_workspace_bytes(int f);
 int wmf_launch_wide_lu(const int32_t* rows, const int32_t* count_ptr, const float* V, const float* biasv,
                        const int64_t* indptr, const int32_t* indices, const float* vals, int f, int ld, float* g,

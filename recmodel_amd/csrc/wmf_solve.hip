@@ -714,6 +714,39 @@ static int dispatch_general(const int32_t* rows, int64_t count, const int32_t* c
     return 0;
 }
 
+// ---- split rows: the partial systems of a row's segments summed into the row's first slot.  One thread per float4 of the
+// system and row, the segments added one after the other (fixed order: results do not depend on the launch), so that a row
+// of a million entries -- 500 segments, tens of megabytes of partial systems -- is combined by hundreds of workgroups and
+// not by the one that eliminates it.
+__global__ __launch_bounds__(256) void combine_segments_kernel(float* __restrict__ partial, const int32_t* __restrict__ seg_first,
+                                                               int64_t heavy_count, int64_t pf4) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= pf4) return;
+    for (int64_t h = blockIdx.y; h < heavy_count; h += gridDim.y) {
+        const int64_t s0 = seg_first[h], s1 = seg_first[h + 1];
+        float4* base = reinterpret_cast<float4*>(partial) + c;
+        float4 a = base[s0 * pf4];
+        int64_t s = s0 + 1;
+        for (; s + 4 <= s1; s += 4) {                            // four loads in flight
+            const float4 b0 = base[s * pf4], b1 = base[(s + 1) * pf4], b2 = base[(s + 2) * pf4], b3 = base[(s + 3) * pf4];
+            a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+            a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+            a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+            a.x += b3.x; a.y += b3.y; a.z += b3.z; a.w += b3.w;
+        }
+        for (; s < s1; ++s) { const float4 b = base[s * pf4]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        base[s0 * pf4] = a;
+    }
+}
+
+void wmf_launch_combine_segments(const wmf_plan* pl, int64_t partial_floats, hipStream_t st) {
+    if (pl->heavy_count <= 0) return;
+    const int64_t pf4 = partial_floats / 4;                      // (every partial layout is a multiple of four floats)
+    const unsigned gy = (unsigned)(pl->heavy_count < 16384 ? pl->heavy_count : 16384);
+    WMF_LAUNCH("combine_segments_kernel", combine_segments_kernel, dim3((unsigned)((pf4 + 255) / 256), gy), dim3(256), 0, st,
+               pl->partial, pl->seg_first, pl->heavy_count, pf4);
+}
+
 int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
                      const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fail_count,
                      hipStream_t st) {
@@ -747,8 +780,7 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
         // f <= 256: four waves per row, tiles owned by block row (wmf_rowsplit.hip); f = 257 .. 272, or debug flag
         // 1024: the run-time-indexed eight-wave kernel (wmf_wide.hip)
         if (wmf_rowsplit_supported(f) && !(wmf_debug_flags & 1024)) {
-            if (wmf_launch_rowsplit(pl->rows[WMF_BIN_GENERAL], pl->count[WMF_BIN_GENERAL], V, biasv, indptr, indices, vals, f, ld,
-                                    g, pl->fallback_rows, pl->fallback_count, st)) return -1;
+            if (wmf_launch_rowsplit(pl, V, biasv, indptr, indices, vals, f, ld, g, st)) return -1;
         } else if (wmf_launch_wide(pl->rows[WMF_BIN_GENERAL], pl->count[WMF_BIN_GENERAL], V, biasv, indptr, indices, vals, f, ld,
                                    g, pl->fallback_rows, pl->fallback_count, st)) return -1;
     }

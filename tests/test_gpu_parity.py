@@ -531,10 +531,11 @@ def test_device_building_blocks_individually():
     assert int(info[0]) == 1 and float(Ww.abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("k,bias", [(32, False), (128, True)])
+@pytest.mark.parametrize("k,bias", [(32, False), (128, True), (256, False), (256, True), (150, False), (176, True)])
 def test_very_heavy_rows_are_split_into_segments(WMF, k, bias):
     """Rows with more than 4096 stored entries (power-law heads) are accumulated by
-    several waves in 2048-entry segments and combined in a fixed order."""
+    several waves (f <= 144) or workgroups (the four-waves-per-row kernel beyond) in 2048-entry segments and
+    combined in a fixed order."""
     rng = np.random.default_rng(9)
     n, m_items = 60, 13000
     degs = [5000, 9000, 13000, 4096, 4097] + [int(x) for x in rng.integers(1, 200, n - 5)]
@@ -548,7 +549,8 @@ def test_very_heavy_rows_are_split_into_segments(WMF, k, bias):
     want = step_o(model.items, as_f64(C), 0.1, out_dtype="float64")
     got = step_g(model.items, C, 0.1)
     rel, _ = worst_row(got, want)
-    assert fro(got, want) <= HALF_FRO and rel <= HALF_ROW, (fro(got, want), rel)
+    tol_fro, tol_row = (HALF_FRO, HALF_ROW) if k + bias <= 144 else (WIDE_FRO, WIDE_ROW)
+    assert fro(got, want) <= tol_fro and rel <= tol_row, (fro(got, want), rel)
     assert np.array_equal(got, step_g(model.items, C, 0.1))          # fixed combination order: bitwise reproducible
 
 
