@@ -83,13 +83,20 @@ int wmf_factorize(const double* G_sum, int f, int ld, double lambda,
                   float* W_white, float* W_unwhite, int32_t* info,
                   void* workspace, void* stream);
 
-/* out[r, :] = in~[r, :] . W  for rows [0, m), in/out [m, ld], W [f, ld].
+/* out[r, :] = in~[r, :] . W  for rows [0, m), in/out [m, ld], W [f, ld]; padding columns are written as zero.
  * set_col0_one != 0 (whitening of the fixed side of a bias model): in~ is `in` with column 0 read as 1, and the bias
- * in[r,0] (wmf_model.py:328-331) is copied to col0_out[r] (may be NULL) AND, for the widths f = 16 m + 1 <= 144 with
- * ld = f + 3 (k = 16, 32, 64, 80, 96, 128 with biases), to out[r, f], the first padding column of the whitened row --
- * where the row kernels of wmf_solve_rows pick it up together with the row itself.  All other padding is written as zero. */
+ * in[r,0] (wmf_model.py:328-331) is copied to col0_out[r] (may be NULL).
+ * SPLIT LAYOUT.  For the widths with wmf_whitened_row_floats(f, ld, 1) == f - 1 -- f = 16 m + 1 <= 144 with ld = f + 3:
+ * k = 16, 32, 64, 80, 96, 128 with biases -- set_col0_one != 0 writes the whitened side in the form the row kernels gather
+ * cheapest: out is a PACKED body, out[r * (f - 1) + c] = feature c < f - 1 of row r (64 m bytes a row, whole 128-byte lines,
+ * where the (f + 3)-float row at its 528-byte stride touched five lines for 4.03 lines of data), and col0_out, then
+ * REQUIRED, is float[2 m]: col0_out[2 r] = feature f - 1, col0_out[2 r + 1] = the bias.  out may not alias in there.
+ * wmf_solve_rows / wmf_accumulate_rows take the two arrays as their V and bias_fixed. */
 int wmf_row_transform(const float* in, int64_t m, int f, int ld, const float* W,
                       int set_col0_one, float* out, float* col0_out, void* stream);
+/* Floats per row of the whitened fixed side that wmf_row_transform(set_col0_one = bias) writes and the row kernels read:
+ * ld, or f - 1 for the split layout above (0: f, ld not supported). */
+int wmf_whitened_row_floats(int f, int ld, int bias);
 
 /* Degree-binned schedule for the rows of one CSR matrix (built once per matrix, host indptr).  Allocates (and
  * synchronously fills) the plan's device memory, including everything wmf_solve_rows will need: the row lists, the
@@ -107,8 +114,8 @@ int  wmf_plan_stats(const wmf_plan* p, int64_t* out12);
 /* The per-row normal-equation solve in whitened coordinates, for every row of the CSR:
  *   g_u = (I + V_u^T D_u V_u)^-1 V_u^T (w_u + 1),   V_u = V[idx_u], D_u = diag(w_u)
  * with w_u = values - bias_fixed[idx_u] when bias_fixed != NULL (wmf_model.py:343).  V and bias_fixed must both come
- * from wmf_row_transform(set_col0_one = 1) on the same matrix: for the widths named there the kernels read the bias
- * from V[idx, f] and never touch bias_fixed (which then only says "this is a bias model").
+ * from wmf_row_transform(set_col0_one = 1) on the same matrix (for the widths named there: packed body and pairs; the
+ * kernels then take the bias with the gathered row, elsewhere one pass over the entries folds it into the weights).
  * g [n, ld]; follow with wmf_row_transform(g, W_unwhite) to obtain X_new.
  * Restates the loop body wmf_model.py:220-239 / 337-350.  Rows without stored entries give 0.
  * fail_count (device int32, caller zeroes): number of rows whose system was numerically singular. */
@@ -185,7 +192,8 @@ int wmf_confidence_transform(float* values, int64_t nnz, double alpha, double be
  *                              entries given (zeros for an empty row).  slot_stride = 1, slot_offset = 0: one slot per
  *                              row.  Larger strides let several calls -- one per arriving chunk of the fixed side --
  *                              fill different slots of the same rows.  degrees = int32[n] device,
- *                              indptr[i + 1] - indptr[i]; bias_fixed != NULL needs w_eff_workspace (float[nnz], device);
+ *                              indptr[i + 1] - indptr[i]; bias_fixed != NULL needs w_eff_workspace (float[nnz], device)
+ *                              unless V / bias_fixed are in the split layout of wmf_row_transform;
  *   wmf_eliminate_rows         g[i] = (I + sum of row i's slots_per_row consecutive slots)^-1 (sum of their y), slots
  *                              added in order; a row whose system is not positive definite is counted in fail_count
  *                              (there is no CSR here to hand to the pivoted fallback); scratch = int32[n] device. */

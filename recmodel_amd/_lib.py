@@ -30,6 +30,7 @@ SIGNATURES = {
     "wmf_gram": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "wmf_factorize": (c_int, [c_vp, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "wmf_row_transform": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "wmf_whitened_row_floats": (c_int, [c_int, c_int, c_int]),
     "wmf_plan_create": (c_int, [c_vp, c_i64, c_int, c_int, ctypes.POINTER(c_vp)]),
     "wmf_plan_destroy": (None, [c_vp]),
     "wmf_plan_stats": (c_int, [c_vp, c_vp]),

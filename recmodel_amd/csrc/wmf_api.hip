@@ -186,8 +186,10 @@ int wmf_row_transform(const float* in, int64_t m, int f, int ld, const float* W,
     int rc = check_shape(f, ld);
     if (rc) return rc;
     if (!in || !W || !out || m < 0) { wmf_set_error("wmf_row_transform: null pointer or negative m"); return WMF_EINVAL; }
-    if (wmf_launch_transform(in, m, f, ld, W, set_col0_one, out, col0_out, (hipStream_t)stream)) {
-        wmf_set_error("wmf_row_transform: unsupported f=%d", f);
+    rc = wmf_launch_transform(in, m, f, ld, W, set_col0_one, out, col0_out, (hipStream_t)stream);
+    if (rc) {
+        if (rc == -3) wmf_set_error("wmf_row_transform: f=%d, ld=%d with set_col0_one writes the split layout: col0_out (float[2 m]) is required and out may not alias in", f, ld);
+        else wmf_set_error("wmf_row_transform: unsupported f=%d", f);
         return WMF_EINVAL;
     }
     return check_launch("wmf_row_transform");
@@ -344,6 +346,11 @@ int wmf_predict_pairs(const float* users, const float* items, int f, int ld, int
 
 int64_t wmf_partial_row_floats(int f) { return wmf_directw_partial_floats(f); }
 
+int wmf_whitened_row_floats(int f, int ld, int bias) {
+    if (check_shape(f, ld)) return 0;
+    return (bias && wmf_split_layout(f, ld)) ? f - 1 : ld;
+}
+
 int wmf_accumulate_rows(const float* V, const float* bias_fixed, const int64_t* indptr, const int32_t* degrees,
                         const int32_t* indices, const float* values, int64_t n, int64_t nnz, int f, int ld, float* partial,
                         int32_t slot_stride, int32_t slot_offset, float* w_eff_workspace, void* stream) {
@@ -362,13 +369,16 @@ int wmf_accumulate_rows(const float* V, const float* bias_fixed, const int64_t* 
                              (size_t)n, st) != hipSuccess) { wmf_set_error("wmf_accumulate_rows: memset failed"); return WMF_EHIP; }
         return WMF_OK;
     }
-    if (bias_fixed) {
-        if (!w_eff_workspace) { wmf_set_error("wmf_accumulate_rows: bias_fixed needs w_eff_workspace"); return WMF_EINVAL; }
+    const float* side = nullptr;
+    if (bias_fixed && wmf_split_layout(f, ld)) {
+        side = bias_fixed;                                        // split layout: the kernel takes the bias from the pairs
+    } else if (bias_fixed) {
+        if (!w_eff_workspace) { wmf_set_error("wmf_accumulate_rows: bias_fixed needs w_eff_workspace at f=%d, ld=%d", f, ld); return WMF_EINVAL; }
         wmf_launch_bias_adjust(values, indices, bias_fixed, nnz, w_eff_workspace, st);
         values = w_eff_workspace;
     }
     {
-        if (wmf_launch_accumulate(V, indptr, degrees, indices, values, n, f, ld, partial, slot_stride, slot_offset, st)) { wmf_set_error("wmf_accumulate_rows: no kernel for f=%d", f); return WMF_EINVAL; }
+        if (wmf_launch_accumulate(V, side, indptr, degrees, indices, values, n, f, ld, partial, slot_stride, slot_offset, st)) { wmf_set_error("wmf_accumulate_rows: no kernel for f=%d", f); return WMF_EINVAL; }
     }
     return check_launch("wmf_accumulate_rows");
 }
@@ -476,7 +486,7 @@ int wmf_recompute_factors_host(const float* Y_host, int64_t m, int f, int bias, 
     const size_t fac_m = (size_t)m * ld * 4, fac_n = (size_t)(n > 0 ? n : 1) * ld * 4;
     if (dY.alloc(fac_m) || dV.alloc(fac_m) || dG.alloc((size_t)f * f * 8) || dWw.alloc((size_t)f * ld * 4) ||
         dWu.alloc((size_t)f * ld * 4) || dInfo.alloc(16) || dWs.alloc((size_t)wmf_gram_workspace_bytes(f)) ||
-        dBias.alloc((size_t)m * 4) || dPtr.alloc((size_t)(n + 1) * 8) || dIdx.alloc((size_t)nnz * 4) ||
+        dBias.alloc((size_t)m * 8) || dPtr.alloc((size_t)(n + 1) * 8) || dIdx.alloc((size_t)nnz * 4) ||
         dVal.alloc((size_t)nnz * 4) || dg.alloc(fac_n) || dX.alloc(fac_n) || dFail.alloc(16)) {
         wmf_set_error("wmf_recompute_factors_host: device allocation failed");
         return WMF_ENOMEM;

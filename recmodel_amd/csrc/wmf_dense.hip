@@ -759,8 +759,8 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
                 for (int e = 0; e < 4; ++e) if (!(c < nch && k0 + e < f)) xe[e] = 0.f;
             }
             if (t == 0 && set_col0_one && q == 0) {
-                if (rok && col0_out && NB0 == 0) col0_out[row] = xe[0];
-                if (rok && set_col0_one == 2 && NB0 == 0) out[row * (int64_t)ld + f] = xe[0];   // the bias rides in the row's first padding column
+                // (set_col0_one == 2, the split layout: col0_out holds {last feature, bias} pairs)
+                if (rok && col0_out && NB0 == 0) col0_out[set_col0_one == 2 ? 2 * row + 1 : row] = xe[0];
                 xe[0] = 1.f;
             }
             unsigned mv = tmask[t];
@@ -788,11 +788,15 @@ __global__ __launch_bounds__(512) void transform_kernel(const float* __restrict_
         for (int reg = 0; reg < 4; ++reg) {
             const int64_t orow = blk * 16 + 4 * q + reg;
             if (orow < m) {
-                float* o = out + orow * (int64_t)ld;
+                // split layout (set_col0_one == 2): packed body rows of f - 1 floats, feature f - 1 goes to the pairs
+                const bool sp = set_col0_one == 2;
+                const int wid = sp ? f - 1 : ld;
+                float* o = out + orow * (int64_t)wid;
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb) {
                     const int col = 16 * (NB0 + nb) + r;
-                    if (col < ld && !(set_col0_one == 2 && col == f)) o[col] = acc[nb][reg];     // (column f: the bias, stored above)
+                    if (col < wid) o[col] = acc[nb][reg];
+                    else if (sp && col == f - 1) col0_out[2 * orow] = acc[nb][reg];
                 }
             }
         }
@@ -889,8 +893,7 @@ __global__ __launch_bounds__(512) void transform6_kernel(const float* __restrict
                 for (int e = 0; e < 8; ++e) if (!(k0 + e < f)) xe[e] = 0.f;
             }
             if (c == 0 && set_col0_one && q == 0) {
-                if (rok && col0_out) col0_out[row] = xe[0];
-                if (rok && set_col0_one == 2) out[row * (int64_t)ld + f] = xe[0];    // the bias rides in the row's first padding column
+                if (rok && col0_out) col0_out[set_col0_one == 2 ? 2 * row + 1 : row] = xe[0];      // (2: the split layout's pairs)
                 xe[0] = 1.f;
             }
             bf16x8_t ah, am, al;
@@ -924,11 +927,15 @@ __global__ __launch_bounds__(512) void transform6_kernel(const float* __restrict
         for (int reg = 0; reg < 4; ++reg) {
             const int64_t orow = blk * 16 + 4 * q + reg;
             if (orow < m) {
-                float* o = out + orow * (int64_t)ld;
+                // split layout (set_col0_one == 2): packed body rows of f - 1 floats, feature f - 1 goes to the pairs
+                const bool sp = set_col0_one == 2;
+                const int wid = sp ? f - 1 : ld;
+                float* o = out + orow * (int64_t)wid;
 #pragma unroll
                 for (int nb = 0; nb < NFB; ++nb) {
                     const int col = 16 * nb + r;
-                    if (col < ld && !(set_col0_one == 2 && col == f)) o[col] = acc[nb][reg];     // (column f: the bias, stored above)
+                    if (col < wid) o[col] = acc[nb][reg];
+                    else if (sp && col == f - 1) col0_out[2 * orow] = acc[nb][reg];
                 }
             }
         }
@@ -1012,9 +1019,9 @@ int wmf_launch_transform(const float* in, int64_t m, int f, int ld, const float*
                          float* col0_out, hipStream_t st) {
     if (m <= 0) return 0;
     const int nfb = (f + 15) / 16;
-    // set_col0_one == 2 inside the kernels: the bias also goes to column f of the output row (wmf_bias_in_pad widths only:
-    // elsewhere the row kernels gather that column as data and rely on its being zero)
-    set_col0_one = set_col0_one ? (wmf_bias_in_pad(f, ld) ? 2 : 1) : 0;
+    // set_col0_one == 2 inside the kernels: the split layout (wmf_internal.h) -- `out` is the packed body, col0_out the pairs
+    set_col0_one = set_col0_one ? (wmf_split_layout(f, ld) ? 2 : 1) : 0;
+    if (set_col0_one == 2 && (!col0_out || in == out)) return -3;
     switch (nfb) {
 #define C(N) case N: launch_transform_nfb<N>(in, m, f, ld, W, set_col0_one, out, col0_out, st); break;
         C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)

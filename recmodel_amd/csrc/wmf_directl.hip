@@ -32,7 +32,7 @@
 #define DL_R 4                      // ring slots = groups per 64-entry block (the group loop is unrolled by it)
 #define DL_W 1024                   // metadata behind the ring: idx[4][64], w[4][64], border[4][64], bias[4][64], block b in buffer b & 3
 #define DL_BD 2048                  // (block b + 1 is requested while groups of b - 1 are still being consumed: three live blocks)
-#define DL_BB 3072                  // the fixed side's bias of the entries: V[idx][f], behind the border feature V[idx][f - 1]
+#define DL_BB 3072                  // the fixed side's bias of the entries (split layout: the second float of their pairs)
 // per width (NFB = 4: f = 64 / 65, NFB = 8: f = 128 / 129): bytes of the feature part of a row, of a 16-entry slot, of the ring
 #define DL_RB(NFB) (64 * (NFB))
 #define DL_SLOTB(NFB) (16 * DL_RB(NFB))
@@ -94,10 +94,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #endif
 template <int NFB, bool BORDER, bool X6>
 __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(const int32_t* __restrict__ rows, int64_t count, const float* __restrict__ V,
-                                                              const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                              const float* __restrict__ side, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                               const float* __restrict__ vals, int f, int ld, float* __restrict__ g,
-                                                              int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int dbg,
-                                                              int bias_in_pad) {
+                                                              int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int dbg) {
+    // side != NULL (BORDER only): the split layout of a bias model's fixed side (wmf_internal.h) -- V holds packed body rows
+    // of f - 1 = 16 NFB floats (exactly the RB bytes a ring row takes), side the {last feature, bias} pairs
+    const bool split = BORDER && side != nullptr;
+    const int ldv = split ? f - 1 : ld;
     constexpr int NT = NFB * (NFB + 1) / 2;
     constexpr int RB = DL_RB(NFB), DL_SLOT = DL_SLOTB(NFB), DL_META = DL_METAB(NFB);   // row bytes, slot bytes, metadata offset
     constexpr int J = NFB / 4;                  // 16-byte pieces per lane and entry (pieces r, r + 16, ..)
@@ -147,11 +150,13 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             float iv = dl_read32<0>(lds0 + DL_META + par + lane * 4);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(iv)::"memory");     // the value passes through the wait: no use can move above it
             const int idx = __builtin_bit_cast(int, iv);
-            __builtin_amdgcn_global_load_lds((dl_gptr)(V + (int64_t)idx * ld + 16 * NFB), (dl_lptr)(smem + DL_META + DL_BD + par), 4, 0, 0);
-            // the fixed side's bias, one float further (wmf_bias_in_pad): same 128-byte line, so a second dword of a request the
-            // border makes anyway.  (A bias vector gathered here instead cost what the separate bias_adjust pass costs.)
-            if (bias_in_pad)
-                __builtin_amdgcn_global_load_lds((dl_gptr)(V + (int64_t)idx * ld + 16 * NFB + 1), (dl_lptr)(smem + DL_META + DL_BB + par), 4, 0, 0);
+            if (split) {
+                // the pair {last feature, bias}: two dwords of one 8-byte word (the pairs of a million rows are 8 MB: L2 hits)
+                __builtin_amdgcn_global_load_lds((dl_gptr)(side + 2 * (int64_t)idx), (dl_lptr)(smem + DL_META + DL_BD + par), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((dl_gptr)(side + 2 * (int64_t)idx + 1), (dl_lptr)(smem + DL_META + DL_BB + par), 4, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds((dl_gptr)(V + (int64_t)idx * ld + 16 * NFB), (dl_lptr)(smem + DL_META + DL_BD + par), 4, 0, 0);
+            }
         }
     };
     // the 16 rows of group gi (S = gi % 4 = its ring slot and its position in the block) -> 8 DMA instructions
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int idx = __builtin_bit_cast(int, ids[i]);
-            __builtin_amdgcn_global_load_lds((dl_gptr)(V + (int64_t)idx * ld + piece), (dl_lptr)(smem + S * DL_SLOT + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((dl_gptr)(V + (int64_t)idx * ldv + piece), (dl_lptr)(smem + S * DL_SLOT + i * 1024), 16, 0, 0);
         }
     };
 
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
                 if (t >= nk) return;                             // wave-uniform: past the row's end
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[B]), "+v"(xb[B]), "+v"(wv[B]), "+v"(bf[B]), "+v"(bb[B])::"memory");
                 const f32x4 ya = xa[B], yb = xb[B];
-                const float wraw = (BORDER && bias_in_pad) ? wv[B] - bb[B] : wv[B], bfv = bf[B];
+                const float wraw = split ? wv[B] - bb[B] : wv[B], bfv = bf[B];
                 if constexpr (t < 3) { if (t + 1 < nk) request(std::integral_constant<int, t + 1>{}); }
                 const bool real = 16 * G + 4 * t + q < d;
                 const float w = real ? wraw : 0.f, p = real ? wraw + 1.f : 0.f;
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const bool real = 16 * G + 8 * q + j < d;
-                const float wraw = (BORDER && bias_in_pad) ? wq[j >> 2][j & 3] - bbq[j >> 2][j & 3] : wq[j >> 2][j & 3];
+                const float wraw = split ? wq[j >> 2][j & 3] - bbq[j >> 2][j & 3] : wq[j >> 2][j & 3];
                 wj[j] = real ? wraw : 0.f;
                 pj[j] = real ? wraw + 1.f : 0.f;
                 swj[j] = DL_S * __builtin_amdgcn_sqrtf(wj[j]);
@@ -443,7 +448,7 @@ int wmf_directl_supported(int f, int ld) {
     return (f == 128 && ld == 128) || (f == 129 && ld == 132) || (f == 64 && ld == 64) || (f == 65 && ld == 68);
 }
 
-int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, bool bias_in_pad, const int64_t* indptr,
+int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows, int32_t* fb_count,
                        hipStream_t st) {
     if (count <= 0) return 0;
@@ -454,7 +459,7 @@ int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, bool 
     const int dbg = wmf_debug_flags;
     const bool x6 = !(dbg & 8192);                              // debug flag 8192: f32 MFMA accumulation
 #define DL_LAUNCH(N, B, X) WMF_LAUNCH("solve_directl_kernel<" #N ", " #B ", " #X ">", (solve_directl_kernel<N, B, X>), grid, dim3(64), \
-                                      DL_LDSB(N), st, rows, count, V, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, (int)bias_in_pad)
+                                      DL_LDSB(N), st, rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg)
 #define DL_PICK(N) do { if (f % 16) { if (x6) DL_LAUNCH(N, true, true); else DL_LAUNCH(N, true, false); } \
                         else        { if (x6) DL_LAUNCH(N, false, true); else DL_LAUNCH(N, false, false); } } while (0)
     if (nfb == 4) DL_PICK(4); else DL_PICK(8);

@@ -87,7 +87,7 @@ __device__ __host__ constexpr int tile_off(int bi, int bj) {     // float offset
 
 template <int NFB, int MODE, bool BORDER>
 __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(const int32_t* __restrict__ rows, int64_t count,
-                                                              const float* __restrict__ V, const float* __restrict__ biasv,
+                                                              const float* __restrict__ V, const float* __restrict__ side,
                                                               const int64_t* __restrict__ indptr,
                                                               const int32_t* __restrict__ indices,
                                                               const float* __restrict__ vals, int f, int ld,
@@ -105,6 +105,9 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
     int baddr[4];
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) baddr[kq] = (r + 16 * kq) * 4;
+    // side != NULL (BORDER only): the split layout of a bias model's fixed side (wmf_internal.h) -- V holds packed body rows
+    // of ldv = f - 1 floats, side the {last feature, bias} pairs; ld stays the stride of g
+    const int ldv = (BORDER && side) ? f - 1 : ld;
 
     // Row pipeline (wmf_stream.h): factor rows are requested DEPTH groups ahead; the next row's first loads
     // are requested before this row's elimination starts.
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
         st.load_block(1, lo_, d_, indices, vals, lane, 1);
         st.fetch_meta(0, q);
         [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
-            (st.template load_group<Ss>(Ss, V, ld, r, q), ...);
+            (st.template load_group<Ss>(Ss, V, ldv, r, q, BORDER ? side : nullptr), ...);
         }(std::make_integer_sequence<int, DEPTH>{});
     };
     if (it < count) prime(lo, d);
@@ -156,12 +159,12 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
 #pragma unroll
                 for (int t = 0; t < GS; ++t) {
                     float fw[NFB];
-                    st.template mask_tail<S>(t, ld, r);
+                    st.template mask_tail<S>(t, ld, r);          // (the row-major width: in the split layout the pair block has no tail)
                     float wt = st.w[S][t], pt = st.p[S][t];
                     if constexpr (BORDER) {
-                        // biasv != NULL: the fixed side's bias sits behind the border feature, in the row's first padding column
-                        // (wmf_bias_in_pad) -- the dword block that brings the border to lane r = 0 brings it to lane r = 1
-                        if (biasv) {
+                        // split layout: the dword block that brings the border feature to lane r = 0 brings the fixed side's
+                        // bias to lane r = 1
+                        if (side) {
                             const bool real = Stream::EPG * G + 4 * t + q < d;
                             const float bs = real ? wmf_dpp<0x151>(st.fr[S][t][NFB]) : 0.f;     // row_newbcast:1
                             wt -= bs;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                     const int c = next / Stream::GPB;
                     st.load_block(c + 1, lo, d, indices, vals, lane, (c + 1) & 1);
                 }
-                st.template load_group<S>(next, V, ld, r, q);
+                st.template load_group<S>(next, V, ldv, r, q, BORDER ? side : nullptr);
             }
         };
         for (int G0 = 0; G0 < ngroups; G0 += DEPTH) {
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
 }
 
 template <int NFB, bool BORDER>
-static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
+static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* side, const int64_t* indptr,
                                const int32_t* indices, const float* vals, int f, int ld, float* g, int dbg, hipStream_t st) {
     constexpr int waves_per_cu = 4 * DwCfg<NFB>::OCC;
     const int64_t cap = 256 * waves_per_cu * 3;                  // resident waves, three rounds queued
@@ -297,13 +300,13 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
     const int64_t normal = pl->count[WMF_BIN_MFMA] - pl->heavy_count;
     // k = 128 with or without biases: the LDS-DMA ring kernel (wmf_directl.hip); debug flag 4096 keeps the register ring
     // (f = 64 / 65 can run there too, debug flag 65536, but gains nothing: cfg2 item side 1.34 ms against 1.30 here)
-    // (biasv is NULL here, or V + f with the bias in the rows' padding: both kernels take the bias from the row itself)
+    // (side: NULL, or the {last feature, bias} pairs of the split layout, V then being the packed body)
     if (normal > 0 && wmf_directl_supported(f, ld) && !(dbg & 4096) && (f >= 128 || (dbg & 65536))) {
-        (void)wmf_launch_directl(rows, normal, V, biasv != nullptr, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, st);
+        (void)wmf_launch_directl(rows, normal, V, side, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, st);
     } else if (normal > 0) {
         static const char* nm = wmf_kname("solve_directw_kernel<%d, 0, %s>", NFB, BORDER ? "true" : "false");
         WMF_LAUNCH(nm, (solve_directw_kernel<NFB, 0, BORDER>), dim3((unsigned)(normal < cap ? normal : cap)), dim3(64), 0, st,
-                   rows, normal, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
+                   rows, normal, V, side, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
                    nullptr, nullptr, nullptr, nullptr, 1, 0);
     }
     if (pl->heavy_count > 0) {
@@ -311,12 +314,12 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
         static const char* nm1 = wmf_kname("solve_directw_kernel<%d, 1, %s>", NFB, BORDER ? "true" : "false");
         static const char* nm2 = wmf_kname("solve_directw_kernel<%d, 2, %s>", NFB, BORDER ? "true" : "false");
         WMF_LAUNCH(nm1, (solve_directw_kernel<NFB, 1, BORDER>), dim3((unsigned)(nseg < cap ? nseg : cap)), dim3(64), 0, st, rows,
-                   nseg, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg, pl->seg_lo,
+                   nseg, V, side, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg, pl->seg_lo,
                    pl->seg_d, pl->seg_first, pl->partial, 1, 0);
         const int64_t nh = pl->heavy_count;
         wmf_launch_combine_segments(pl, WMF_DW_PARTIAL(NFB, BORDER), st);
         WMF_LAUNCH(nm2, (solve_directw_kernel<NFB, 2, BORDER>), dim3((unsigned)(nh < cap ? nh : cap)), dim3(64), 0, st,
-                   rows + normal, nh, V, biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
+                   rows + normal, nh, V, side, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
                    pl->seg_lo, pl->seg_d, pl->seg_first, pl->partial, 0, 0);
     }
 }
@@ -324,13 +327,13 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
 // Partial systems for the reduce-scatter exchange (engine.py, "reduce mode"): MODE 1 over every row of a CSR (one
 // segment per row, slot = row) and MODE 2 over a buffer of summed partial systems (one slot per row, row = slot).
 template <int NFB, bool BORDER>
-static void launch_accumulate_nfb(const float* V, const int64_t* indptr, const int32_t* degrees, const int32_t* indices,
+static void launch_accumulate_nfb(const float* V, const float* side, const int64_t* indptr, const int32_t* degrees, const int32_t* indices,
                                   const float* vals, int64_t n, int f, int ld, float* partial, int slot_stride, int slot_offset,
                                   hipStream_t st) {
     const int64_t cap = 256 * 4 * DwCfg<NFB>::OCC * 3;
     static const char* nm = wmf_kname("solve_directw_kernel<%d, 1, %s>", NFB, BORDER ? "true" : "false");
     WMF_LAUNCH(nm, (solve_directw_kernel<NFB, 1, BORDER>), dim3((unsigned)(n < cap ? n : cap)), dim3(64), 0, st, nullptr, n, V,
-               nullptr, indptr, indices, vals, f, ld, nullptr, nullptr, nullptr, wmf_debug_flags & ~3, indptr, degrees,
+               side, indptr, indices, vals, f, ld, nullptr, nullptr, nullptr, wmf_debug_flags & ~3, indptr, degrees,
                nullptr, partial, slot_stride, slot_offset);
 }
 template <int NFB, bool BORDER>
@@ -350,14 +353,14 @@ int64_t wmf_directw_partial_floats(int f) {
     return nfb * (nfb - 1) / 2 * 256 + nfb * WMF_DW_TRI + (nfb + (dw_border(f) ? nfb + 2 : 0)) * 64;
 }
 
-int wmf_launch_accumulate(const float* V, const int64_t* indptr, const int32_t* degrees, const int32_t* indices,
+int wmf_launch_accumulate(const float* V, const float* side, const int64_t* indptr, const int32_t* degrees, const int32_t* indices,
                           const float* vals, int64_t n, int f, int ld, float* partial, int slot_stride, int slot_offset,
                           hipStream_t st) {
     if (n <= 0) return 0;
     if (f > 144) return -1;
     if (dw_border(f)) {
         switch (f / 16) {
-#define C_(N) case N: launch_accumulate_nfb<N, true>(V, indptr, degrees, indices, vals, n, f, ld, partial, slot_stride, slot_offset, st); break;
+#define C_(N) case N: launch_accumulate_nfb<N, true>(V, side, indptr, degrees, indices, vals, n, f, ld, partial, slot_stride, slot_offset, st); break;
             C_(1) C_(2) C_(4) C_(5) C_(6) C_(8)
 #undef C_
             default: return -1;
@@ -365,7 +368,7 @@ int wmf_launch_accumulate(const float* V, const int64_t* indptr, const int32_t* 
         return 0;
     }
     switch ((f + 15) / 16) {
-#define C_(N) case N: launch_accumulate_nfb<N, false>(V, indptr, degrees, indices, vals, n, f, ld, partial, slot_stride, slot_offset, st); break;
+#define C_(N) case N: launch_accumulate_nfb<N, false>(V, nullptr, indptr, degrees, indices, vals, n, f, ld, partial, slot_stride, slot_offset, st); break;
         C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9)
 #undef C_
         default: return -1;
@@ -395,7 +398,7 @@ int wmf_launch_eliminate(float* partial, int64_t n, int slots_per_row, int f, in
     return 0;
 }
 
-int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
+int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* side, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int f, int ld, float* g, hipStream_t st) {
     if (pl->count[WMF_BIN_MFMA] <= 0) return 0;
     const int dbg = wmf_debug_flags;
@@ -403,7 +406,7 @@ int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* biasv, c
     // dword block (lane 0), which it does unless m + 1 is a multiple of 4 (then all blocks are 16-byte pieces).
     if (dw_border(f)) {
         switch (f / 16) {
-#define C_(N) case N: launch_directw_nfb<N, true>(pl, V, biasv, indptr, indices, vals, f, ld, g, dbg, st); break;
+#define C_(N) case N: launch_directw_nfb<N, true>(pl, V, side, indptr, indices, vals, f, ld, g, dbg, st); break;
             C_(1) C_(2) C_(4) C_(5) C_(6) C_(8)
 #undef C_
             default: return -1;
@@ -411,7 +414,7 @@ int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* biasv, c
         return 0;
     }
     switch ((f + 15) / 16) {
-#define C_(N) case N: launch_directw_nfb<N, false>(pl, V, biasv, indptr, indices, vals, f, ld, g, dbg, st); break;
+#define C_(N) case N: launch_directw_nfb<N, false>(pl, V, side, indptr, indices, vals, f, ld, g, dbg, st); break;
         C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9)
 #undef C_
         default: return -1;

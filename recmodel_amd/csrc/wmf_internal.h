@@ -51,19 +51,24 @@ static inline int wmf_direct_supported(int f) { return f >= 1 && f <= 144; }   /
 // Widths whose last feature is a border column of an m-block system (f = 16 m + 1 <= 144, m + 1 not a multiple of 4; debug
 // flag 256 switches the border off): k = 16 m with biases.
 static inline bool wmf_dw_border(int f) { return f > 16 && f <= 144 && f % 16 == 1 && (f / 16) % 4 != 3 && !(wmf_debug_flags & 256); }
-// For those widths the whitened row V[i] (ld = f + 3 floats) carries its side's bias in the first padding column, V[i][f]
-// (written by wmf_row_transform(set_col0_one = 1)): the row kernels subtract it from the entry weights as the row arrives
-// (RecModel/wmf_model.py:343) instead of a separate pass over all entries that gathers it from a bias vector.
-static inline bool wmf_bias_in_pad(int f, int ld) { return wmf_dw_border(f) && ld == f + 3; }
+// SPLIT LAYOUT of the whitened fixed side of a bias model at those widths (ld = f + 3): the first f - 1 = 16 m features of
+// row i are a packed body row V[i * (f - 1) ..] -- 64 m bytes, whole 128-byte lines when m is even, where an (f + 3)-float
+// row at a 528-byte stride (f = 129) touched five lines for 4.03 lines of data -- and the last feature and the side's bias are
+// the pair side[2 i], side[2 i + 1] of a small second array (8 bytes per row: 8 MB for a million items, resident in L2 /
+// Infinity Cache).  The row kernels subtract the bias from the entry weights as it arrives (RecModel/wmf_model.py:343): no
+// separate pass over all entries.  Written by wmf_row_transform(set_col0_one = 1), read by every row kernel of
+// wmf_solve_rows / wmf_accumulate_rows when a bias array is given.
+static inline bool wmf_split_layout(int f, int ld) { return wmf_dw_border(f) && ld == f + 3; }
 // wmf_directl.hip: normal heavy rows at f = 128 / 129 through an LDS-DMA row ring
 int wmf_directl_supported(int f, int ld);
-int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, bool bias_in_pad, const int64_t* indptr,
+// (side: NULL, or the {last feature, bias} pairs of the split layout; V is then the packed body)
+int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows, int32_t* fb_count,
                        hipStream_t st);
-int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
+int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* side, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int f, int ld, float* g, hipStream_t st);
 int64_t wmf_directw_partial_floats(int f);
-int wmf_launch_accumulate(const float* V, const int64_t* indptr, const int32_t* degrees, const int32_t* indices,
+int wmf_launch_accumulate(const float* V, const float* side, const int64_t* indptr, const int32_t* degrees, const int32_t* indices,
                           const float* vals, int64_t n, int f, int ld, float* partial, int slot_stride, int slot_offset,
                           hipStream_t st);
 int wmf_launch_eliminate(float* partial, int64_t n, int slots_per_row, int f, int ld, float* g, int32_t* fb_rows,

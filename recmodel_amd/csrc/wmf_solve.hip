@@ -85,12 +85,33 @@ __device__ __forceinline__ void gj_sweep(float (&m)[NSETS][NSETS * 4], float (&p
 #endif
 // d <= 16 rows are latency bound: six waves per SIMD (<= 80 registers, no spills up to NCH = 9) measured 15 % faster
 // than the five the compiler settles on at k = 128; the d <= 32 kernel needs its 100 registers.
-// X6 (NSETS == 2, ld a multiple of 32): the three S tiles by split-bf16 products.  A lane then takes the pieces
-// 8 c + 2 q, 8 c + 2 q + 1 of its rows (the eight k of chunk c's 16x16x32 MFMA operand) instead of 4 t + q; every gathered
-// value is split into three bf16 parts (exact) and each tile gets six bf16 MFMAs per 32 features instead of eight f32
-// ones.  A bf16 MFMA holds the SIMD's shared pipe for 8 of its 16 cycles, an f32 one for all 32: with five waves per SIMD the
-// other waves' VALU work runs beside it.
-typedef __bf16 low_bf16x8 __attribute__((ext_vector_type(8)));
+// X6 (the row's features are whole 32-feature chunks -- ld a multiple of 32 -- or whole chunks and ONE more 16-byte piece:
+// f = 32 c + 1 with ld = f + 3, e.g. k = 128 with biases, row-major or in the split layout): the S tiles by split-f16
+// products.  A lane then takes the pieces 8 c + 2 q, 8 c + 2 q + 1 of its rows (the eight k of chunk c's 16x16x32 MFMA
+// operand) instead of 4 t + q; every gathered value, scaled by 2^8, is split into two f16 parts x = hi + lo (22 bits) and
+// each tile gets three f16 MFMAs per 32 features (lo.hi, hi.lo, hi.hi) instead of eight f32 ones; the odd last piece is one
+// f32 MFMA step.  An f16 MFMA holds the SIMD's pipe for 8 of its 16 cycles, an f32 one for all 32 -- and these kernels are
+// bound by exactly that pipe (fetching 20 % fewer bytes per row left solve_low<9, 1> at cfg3 where it was, 8.6 ms).
+// Whitened rows have |v| <= 1 (V^T V <= I), so the scaled values stay far below the f16 range, and their low parts (2^-11
+// of the value) stay normal f16 numbers down to |v| ~ 5e-4; the error of a tile entry is that of its f32 accumulation
+// (the rounds before this used three bf16 parts and six MFMAs: exact split, twice the MFMA time).
+typedef _Float16 low_f16x8 __attribute__((ext_vector_type(8)));
+#define WMF_LOW_SC 256.f
+template <int E> __device__ __forceinline__ float low_elem(const float4& a, const float4& b) {
+    return E == 0 ? a.x : E == 1 ? a.y : E == 2 ? a.z : E == 3 ? a.w : E == 4 ? b.x : E == 5 ? b.y : E == 6 ? b.z : b.w;
+}
+// the two f16 parts of the eight values of pieces (a, b), scaled
+__device__ __forceinline__ void low_split8(const float4& a, const float4& b, low_f16x8& hi, low_f16x8& lo) {
+    const float xe[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma clang fp contract(off)                       // (with contraction hipcc forms the high part twice, differently rounded)
+        const float sx = xe[e] * WMF_LOW_SC;
+        const _Float16 h = (_Float16)sx;
+        hi[e] = h;
+        lo[e] = (_Float16)(sx - (float)h);
+    }
+}
 template <int NCH, int NSETS, bool BLK, bool X6 = false>
 __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 4) ? 5 : 1)) void solve_low_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                         const float* __restrict__ V, const float* __restrict__ biasv,
@@ -98,9 +119,9 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
                                                         const int32_t* __restrict__ indices,
                                                         const float* __restrict__ vals, int ld, int last1, float* __restrict__ g,
                                                         int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int bstride) {
-    // biasv / bstride: the fixed side's bias of row idx is biasv[idx * bstride] -- a bias vector (bstride = 1), or the first
-    // padding column of the whitened rows themselves (biasv = V + f, bstride = ld: wmf_bias_in_pad), which the gathers
-    // below then have to keep out of the products
+    // biasv / bstride: bstride = 1: biasv[idx] is the fixed side's bias of row idx.  bstride = 2: the SPLIT LAYOUT
+    // (wmf_internal.h): V holds packed body rows of ld - 4 floats, biasv the pairs {last feature, bias} of the rows -- the
+    // last 16-byte piece of a gathered row is then made of the pair, which every lane of the entry loads (8 bytes, L2)
     const int lane = threadIdx.x & 63;
     // wave-uniform values are forced into SGPRs: hipcc cannot see that threadIdx.x >> 6 is uniform, and
     // would otherwise predicate every `k < d` step with exec masks and register copies
@@ -114,6 +135,7 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
     const int d = __builtin_amdgcn_readfirstlane((int)(indptr[u + 1] - lo));
     const int r = lane & 15, q = lane >> 4;
     const int nch = ld >> 2;
+    const int vch = bstride == 2 ? nch - 1 : nch;   // 16-byte pieces of a stored row of V
 
     // All loads are unconditional and clamped to a stored entry (under a per-lane select hipcc sinks the load
     // into a branch and waits for each in turn).  Slots j >= d read the factor row of entry 0 -- real, finite
@@ -124,8 +146,9 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
     float4 x[NSETS][NCH];
     bool neg = false;
     const float4* Vq = reinterpret_cast<const float4*>(V) + q;      // this lane's pieces are q, q+4, q+8, ...
-    const int last_c = min(4 * (NCH - 1) + q, nch - 1);
-    const float last_m = (4 * (NCH - 1) + q < nch) ? 1.f : 0.f;
+    constexpr bool TAIL = X6 && (NCH & 1);          // X6: whole chunks and one more piece, the row's last (lane q = 0 owns it)
+    const int last_c = TAIL ? nch - 1 : min(4 * (NCH - 1) + q, nch - 1);
+    const float last_m = TAIL ? (q == 0 ? 1.f : 0.f) : ((4 * (NCH - 1) + q < nch) ? 1.f : 0.f);
 #pragma unroll
     for (int s = 0; s < NSETS; ++s) {
         const int j = r + 16 * s;
@@ -134,17 +157,22 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
         const int idx = indices[e];
         float wj = vals[e];
         if (biasv && bstride == 1) wj -= biasv[idx];
-        const float4* vrow = Vq + (int64_t)idx * nch;
-        if constexpr (X6) {                          // pieces 8 c + 2 q + h, all inside the row (ld is a multiple of 32)
+        const float4* vrow = Vq + (int64_t)idx * vch;
+        if constexpr (X6) {                          // pieces 8 c + 2 q + h of the whole chunks
 #pragma unroll
-            for (int t = 0; t < NCH; ++t) x[s][t] = (vrow - q)[8 * (t >> 1) + 2 * q + (t & 1)];
+            for (int t = 0; t < NCH - (TAIL ? 1 : 0); ++t) x[s][t] = (vrow - q)[8 * (t >> 1) + 2 * q + (t & 1)];
         } else {
 #pragma unroll
             for (int t = 0; t < NCH - 1; ++t) x[s][t] = vrow[4 * t];
-            const float4 v = (vrow - q)[last_c];
-            // Bias in the padding (bstride > 1): f = 4 (nch - 1) + 1, the row's last piece is { feature f - 1, bias, 0, 0 }, and
-            // it is the piece EVERY lane of the entry has just loaded (q = 0 owns it, the others were clamped to it): the
-            // bias costs no load of its own.
+        }
+        if constexpr (!X6 || TAIL) {
+            float4 v;
+            if (bstride == 2) {                          // split layout: f = 4 (nch - 1) + 1, the last piece is { feature f - 1, bias, 0, 0 }
+                const float2 sd = reinterpret_cast<const float2*>(biasv)[idx];
+                v = make_float4(sd.x, sd.y, 0.f, 0.f);
+            } else {
+                v = (vrow - q)[last_c];
+            }
             const float pad_m = (bstride > 1) ? 0.f : last_m;
             if (bstride > 1) wj -= v.y;
             x[s][NCH - 1] = make_float4(v.x * last_m, v.y * pad_m, v.z * last_m, v.w * last_m);
@@ -182,35 +210,36 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
 #pragma unroll
             for (int c = 0; c < NSETS; ++c) acc[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (X6) {
-            static_assert(NSETS == 2 && NCH % 2 == 0, "X6: two sets, whole 32-feature chunks");
+            constexpr int NKC = (NCH - (TAIL ? 1 : 0)) / 2;
+            static_assert(NKC >= 1 && 2 * NKC + (TAIL ? 1 : 0) == NCH, "X6: whole 32-feature chunks, at most one more piece");
 #pragma unroll
-            for (int cc = 0; cc < NCH / 2; ++cc) {
-                low_bf16x8 hi[2], mid[2], lo[2];
+            for (int cc = 0; cc < NKC; ++cc) {
+                low_f16x8 hi[NSETS], lo[NSETS];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const float xe[8] = {x[s][2 * cc].x, x[s][2 * cc].y, x[s][2 * cc].z, x[s][2 * cc].w,
-                                         x[s][2 * cc + 1].x, x[s][2 * cc + 1].y, x[s][2 * cc + 1].z, x[s][2 * cc + 1].w};
+                for (int s = 0; s < NSETS; ++s) low_split8(x[s][2 * cc], x[s][2 * cc + 1], hi[s], lo[s]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const __bf16 h = (__bf16)xe[e];
-                        const float r1 = xe[e] - (float)h;
-                        const __bf16 md = (__bf16)r1;
-                        hi[s][e] = h; mid[s][e] = md; lo[s][e] = (__bf16)(r1 - (float)md);
+                for (int s = 0; s < NSETS; ++s)
+#pragma unroll
+                    for (int c = s; c < NSETS; ++c) {             // tile (s, c): A from set c, B from set s, as the f32 path
+                        // (NSETS == 1: two accumulation chains, even and odd chunks)
+                        f32x4 a = (NSETS == 1 && (cc & 1)) ? acc1 : acc[s][c];
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo[c], hi[s], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi[c], lo[s], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi[c], hi[s], a, 0, 0, 0);
+                        if (NSETS == 1 && (cc & 1)) acc1 = a; else acc[s][c] = a;
                     }
-                }
+            }
+            constexpr float UNSC = 1.f / (WMF_LOW_SC * WMF_LOW_SC);
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < NSETS; ++s)
 #pragma unroll
-                    for (int c = s; c < 2; ++c) {                 // tile (s, c): A from set c, B from set s, as the f32 path
-                        f32x4 a = acc[s][c];
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo[c], hi[s], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[c], mid[s], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[c], lo[s], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[c], hi[s], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[c], mid[s], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[c], hi[s], a, 0, 0, 0);
-                        acc[s][c] = a;
-                    }
+                for (int c = s; c < NSETS; ++c) acc[s][c] *= UNSC;
+            acc1 *= UNSC;
+            if constexpr (TAIL) {                    // the row's last piece holds one feature (and, bias models, the bias: masked)
+#pragma unroll
+                for (int s = 0; s < NSETS; ++s)
+#pragma unroll
+                    for (int c = s; c < NSETS; ++c) acc[s][c] = WMF_MFMA16(x[c][NCH - 1].x, x[s][NCH - 1].x, acc[s][c]);
             }
         }
 #pragma unroll
@@ -351,7 +380,8 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
 #if !(WMF_LOW_ABLATE & 4)
         wmf_row16_sum4(y.x, y.y, y.z, y.w);
 #endif
-        const int c = X6 ? 8 * (t >> 1) + 2 * q + (t & 1) : 4 * t + q;      // the piece this lane holds in slot t
+        // the piece this lane holds in slot t (X6 with a last odd piece: lane q = 0 owns it)
+        const int c = X6 ? ((TAIL && t == NCH - 1) ? (q == 0 ? nch - 1 : nch) : 8 * (t >> 1) + 2 * q + (t & 1)) : 4 * t + q;
         if (r == 0 && c < nch) grow[c] = y;
     }
 }
@@ -362,7 +392,7 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
 // formed), one Gauss-Jordan sweep solves both systems (steps 0..7 belong to A, 8..15 to B), and the DPP sums of
 // g = V_u^T c stop after three stages: half the MFMAs and two thirds of the VALU work per row of solve_low<NCH, 1>.
 // A third of cfg3's users (Poisson(10) degrees) and most users of a power-law data set are such rows.
-template <int NCH>
+template <int NCH, bool X6 = false>
 __global__ __launch_bounds__(256, NCH <= 9 ? 6 : 1) void solve_pair_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                                           const float* __restrict__ V, const float* __restrict__ biasv,
                                                                           const int64_t* __restrict__ indptr,
@@ -391,14 +421,26 @@ __global__ __launch_bounds__(256, NCH <= 9 ? 6 : 1) void solve_pair_kernel(const
     if (biasv && bstride == 1) wj -= biasv[idx];
     float4 x[NCH];
     const float4* Vq = reinterpret_cast<const float4*>(V) + q;
-    const int last_c = min(4 * (NCH - 1) + q, nch - 1);
-    const float last_m = (4 * (NCH - 1) + q < nch) ? 1.f : 0.f;
-    const float4* vrow = Vq + (int64_t)idx * nch;
+    constexpr bool TAIL = X6 && (NCH & 1);           // X6 (solve_low_kernel): whole 32-feature chunks and at most one more piece
+    const int last_c = TAIL ? nch - 1 : min(4 * (NCH - 1) + q, nch - 1);
+    const float last_m = TAIL ? (q == 0 ? 1.f : 0.f) : ((4 * (NCH - 1) + q < nch) ? 1.f : 0.f);
+    const float4* vrow = Vq + (int64_t)idx * (bstride == 2 ? nch - 1 : nch);
+    if constexpr (X6) {
 #pragma unroll
-    for (int t = 0; t < NCH - 1; ++t) x[t] = vrow[4 * t];
-    {
-        const float4 v = (vrow - q)[last_c];
-        const float pad_m = (bstride > 1) ? 0.f : last_m;    // (bias in the padding: every lane holds it in v.y, see solve_low_kernel)
+        for (int t = 0; t < NCH - (TAIL ? 1 : 0); ++t) x[t] = (vrow - q)[8 * (t >> 1) + 2 * q + (t & 1)];
+    } else {
+#pragma unroll
+        for (int t = 0; t < NCH - 1; ++t) x[t] = vrow[4 * t];
+    }
+    if constexpr (!X6 || TAIL) {
+        float4 v;
+        if (bstride == 2) {                              // split layout: the last piece from the {last feature, bias} pair (solve_low_kernel)
+            const float2 sd = reinterpret_cast<const float2*>(biasv)[idx];
+            v = make_float4(sd.x, sd.y, 0.f, 0.f);
+        } else {
+            v = (vrow - q)[last_c];
+        }
+        const float pad_m = (bstride > 1) ? 0.f : last_m;
         if (bstride > 1) wj -= v.y;
         x[NCH - 1] = make_float4(v.x * last_m, v.y * pad_m, v.z * last_m, v.w * last_m);
     }
@@ -418,8 +460,25 @@ __global__ __launch_bounds__(256, NCH <= 9 ? 6 : 1) void solve_pair_kernel(const
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) baddr[kq] = (r + 16 * kq) * 4;
     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (X6) {                              // split-f16 products, two chains (even and odd chunks)
+        constexpr int NKC = (NCH - (TAIL ? 1 : 0)) / 2;
+        static_assert(NKC >= 1 && 2 * NKC + (TAIL ? 1 : 0) == NCH, "X6: whole 32-feature chunks, at most one more piece");
 #pragma unroll
-    for (int t = 0; t < NCH; ++t) {
+        for (int cc = 0; cc < NKC; ++cc) {
+            low_f16x8 hi, lo;
+            low_split8(x[2 * cc], x[2 * cc + 1], hi, lo);
+            f32x4 a = (cc & 1) ? a1 : a0;
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, hi, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, lo, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, hi, a, 0, 0, 0);
+            if (cc & 1) a1 = a; else a0 = a;
+        }
+        constexpr float UNSC = 1.f / (WMF_LOW_SC * WMF_LOW_SC);
+        a0 *= UNSC; a1 *= UNSC;
+        if constexpr (TAIL) a0 = WMF_MFMA16(x[NCH - 1].x, x[NCH - 1].x, a0);
+    }
+#pragma unroll
+    for (int t = 0; t < (X6 ? 0 : NCH); ++t) {
         a0 = WMF_MFMA16(x[t].x, x[t].x, a0);
         if (!((t == NCH - 1) && last1)) {              // (a last piece of one feature and three padding zeros: solve_low_kernel)
             a1 = WMF_MFMA16(x[t].y, x[t].y, a1);
@@ -445,7 +504,7 @@ __global__ __launch_bounds__(256, NCH <= 9 ? 6 : 1) void solve_pair_kernel(const
     for (int t = 0; t < NCH; ++t) {
         float4 y = make_float4(p[0] * x[t].x, p[0] * x[t].y, p[0] * x[t].z, p[0] * x[t].w);
         wmf_row8_sum4(y.x, y.y, y.z, y.w);
-        const int c = 4 * t + q;
+        const int c = X6 ? ((TAIL && t == NCH - 1) ? (q == 0 ? nch - 1 : nch) : 8 * (t >> 1) + 2 * q + (t & 1)) : 4 * t + q;
         if (writer && c < nch) grow[c] = y;
     }
 }
@@ -462,8 +521,8 @@ __global__ __launch_bounds__(256) void solve_general_kernel(const int32_t* __res
                                                             const int32_t* __restrict__ indices,
                                                             const float* __restrict__ vals, int f, int ld,
                                                             float* __restrict__ g, int32_t* __restrict__ fail_count, int bstride) {
-    // (bias in the padding, bstride = ld: column f of the staged rows holds it; only the leading f x f block and the first f
-    // entries of the right-hand side are ever used)
+    // (split layout, bstride = 2: V is the packed body, biasv the {last feature, bias} pairs; column f of the staged rows then
+    // holds the bias, and only the leading f x f block and the first f entries of the right-hand side are ever used)
     constexpr int FP = 16 * NFB;
     constexpr int LDV = FP + 4;          // staging row stride (floats), keeps 16-byte alignment
     constexpr int LDB = FP + 1;          // odd: conflict-free column walks
@@ -497,13 +556,19 @@ __global__ __launch_bounds__(256) void solve_general_kernel(const int32_t* __res
             for (int e = tid; e < nrow * nch; e += 256) {
                 const int j = e / nch, c = e % nch;
                 const int idx = indices[lo + base + j];
-                const float4 v = reinterpret_cast<const float4*>(V + (int64_t)idx * ld)[c];
+                float4 v;
+                if (bstride == 2 && c == nch - 1) {
+                    const float2 sd = reinterpret_cast<const float2*>(biasv)[idx];
+                    v = make_float4(sd.x, sd.y, 0.f, 0.f);
+                } else {
+                    v = reinterpret_cast<const float4*>(V + (int64_t)idx * (bstride == 2 ? ld - 4 : ld))[c];
+                }
                 *reinterpret_cast<float4*>(&Vs[j * LDV + 4 * c]) = v;
             }
             if (tid < nrow) {
                 const int idx = indices[lo + base + tid];
                 float wj = vals[lo + base + tid];
-                if (biasv) wj -= biasv[(int64_t)idx * bstride];
+                if (biasv) wj -= biasv[bstride == 2 ? 2 * (int64_t)idx + 1 : (int64_t)idx];
                 ws[tid] = wj;
             }
             __syncthreads();
@@ -649,40 +714,40 @@ static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, i
     const int64_t c0 = pl->count[WMF_BIN_LOW16], c1 = pl->count[WMF_BIN_LOW32];
     // rows with at most 8 entries come first in the bin and go two per wave (solve_pair_kernel)
     const int64_t c8 = (wmf_debug_flags & 2048) ? 0 : pl->count8;
+    // split-f16 S tiles (X6, solve_low_kernel) where the row is whole 32-feature chunks, or those and one more piece
+    // (debug flag 524288: f32 MFMAs everywhere)
+    constexpr bool X6_OK = (NCH % 2 == 0) || (NCH >= 3);
+    const bool x6 = X6_OK && !(wmf_debug_flags & 524288) && ((NCH % 2 == 0) ? (ld % 32 == 0) : (last1 && ld == 16 * (NCH - 1) + 4));   // (last1: f = ld - 3, one feature in the last piece)
+#define WMF_LOW_LAUNCH(KERNEL, NAME, ROWS, COUNT, GRID)                                                                   \
+    do {                                                                                                                  \
+        static const char* nm_ = NAME;                                                                                     \
+        WmfProfScope ps_(nm_, st);                                                                                         \
+        hipLaunchKernelGGL(KERNEL, dim3((unsigned)(GRID)), dim3(256), 0, st, ROWS, COUNT, V, biasv, indptr, indices, vals,  \
+                           ld, last1, g, pl->fallback_rows, pl->fallback_count, bstride);                                   \
+    } while (0)
     if (c8 > 0) {
-        static const char* nm = wmf_kname("solve_pair_kernel<%d>", NCH);
-        WmfProfScope ps(nm, st);
-        hipLaunchKernelGGL((solve_pair_kernel<NCH>), dim3((unsigned)(((c8 + 1) / 2 + 3) / 4)), dim3(256), 0, st,
-                           pl->rows[WMF_BIN_LOW16], c8, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
-                           pl->fallback_count, bstride);
+        if constexpr (X6_OK) {
+            if (x6) WMF_LOW_LAUNCH((solve_pair_kernel<NCH, true>), wmf_kname("solve_pair_kernel<%d, true>", NCH), pl->rows[WMF_BIN_LOW16], c8, ((c8 + 1) / 2 + 3) / 4);
+        }
+        if (!x6) WMF_LOW_LAUNCH((solve_pair_kernel<NCH, false>), wmf_kname("solve_pair_kernel<%d, false>", NCH), pl->rows[WMF_BIN_LOW16], c8, ((c8 + 1) / 2 + 3) / 4);
     }
     if (c0 - c8 > 0) {
-        static const char* nm = wmf_kname("solve_low_kernel<%d, 1, false, false>", NCH);
-        WmfProfScope ps(nm, st);
-        hipLaunchKernelGGL((solve_low_kernel<NCH, 1, false>), dim3((unsigned)((c0 - c8 + 3) / 4)), dim3(256), 0, st,
-                           pl->rows[WMF_BIN_LOW16] + c8, c0 - c8, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
-                           pl->fallback_count, bstride);
+        if constexpr (X6_OK) {
+            if (x6) WMF_LOW_LAUNCH((solve_low_kernel<NCH, 1, false, true>), wmf_kname("solve_low_kernel<%d, 1, false, true>", NCH), pl->rows[WMF_BIN_LOW16] + c8, c0 - c8, (c0 - c8 + 3) / 4);
+        }
+        if (!x6) WMF_LOW_LAUNCH((solve_low_kernel<NCH, 1, false, false>), wmf_kname("solve_low_kernel<%d, 1, false, false>", NCH), pl->rows[WMF_BIN_LOW16] + c8, c0 - c8, (c0 - c8 + 3) / 4);
     }
     if (c1 > 0) {
-        static const char* nm_gj = wmf_kname("solve_low_kernel<%d, 2, false, false>", NCH);
-        static const char* nm_x6 = wmf_kname("solve_low_kernel<%d, 2, true, true>", NCH);
-        static const char* nm_blk = wmf_kname("solve_low_kernel<%d, 2, true, false>", NCH);
-        const bool x6 = NCH % 2 == 0 && ld % 32 == 0 && !(wmf_debug_flags & 524288);
-        WmfProfScope ps((wmf_debug_flags & 64) ? nm_gj : (x6 ? nm_x6 : nm_blk), st);
-        if (wmf_debug_flags & 64)       // plain 32 x 32 Gauss-Jordan, kept for A/B timing
-            hipLaunchKernelGGL((solve_low_kernel<NCH, 2, false>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
-                               pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
-                               pl->fallback_count, bstride);
-        else if (NCH % 2 == 0 && ld % 32 == 0 && !(wmf_debug_flags & 524288)) {    // split-bf16 S tiles (flag 524288: f32)
-            if constexpr (NCH % 2 == 0)
-                hipLaunchKernelGGL((solve_low_kernel<NCH, 2, true, true>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
-                                   pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
-                                   pl->fallback_count, bstride);
-        } else
-            hipLaunchKernelGGL((solve_low_kernel<NCH, 2, true>), dim3((unsigned)((c1 + 3) / 4)), dim3(256), 0, st,
-                               pl->rows[WMF_BIN_LOW32], c1, V, biasv, indptr, indices, vals, ld, last1, g, pl->fallback_rows,
-                               pl->fallback_count, bstride);
+        if (wmf_debug_flags & 64) {     // plain 32 x 32 Gauss-Jordan, kept for A/B timing
+            WMF_LOW_LAUNCH((solve_low_kernel<NCH, 2, false, false>), wmf_kname("solve_low_kernel<%d, 2, false, false>", NCH), pl->rows[WMF_BIN_LOW32], c1, (c1 + 3) / 4);
+        } else {
+            if constexpr (X6_OK) {
+                if (x6) WMF_LOW_LAUNCH((solve_low_kernel<NCH, 2, true, true>), wmf_kname("solve_low_kernel<%d, 2, true, true>", NCH), pl->rows[WMF_BIN_LOW32], c1, (c1 + 3) / 4);
+            }
+            if (!x6) WMF_LOW_LAUNCH((solve_low_kernel<NCH, 2, true, false>), wmf_kname("solve_low_kernel<%d, 2, true, false>", NCH), pl->rows[WMF_BIN_LOW32], c1, (c1 + 3) / 4);
+        }
     }
+#undef WMF_LOW_LAUNCH
 }
 
 template <int NFB>
@@ -755,9 +820,10 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
     if (nnz == 0)                                                      // nothing stored: every row solves to zero
         return hipMemsetAsync(g, 0, (size_t)pl->n * ld * sizeof(float), st) == hipSuccess ? 0 : -2;
     int bstride = 1;
-    if (biasv && wmf_bias_in_pad(f, ld)) {                             // the bias arrives with the gathered row (column f of V)
-        biasv = V + f;
-        bstride = ld;
+    const float* side = nullptr;
+    if (biasv && wmf_split_layout(f, ld)) {                            // split layout: V is the packed body, biasv the pairs
+        side = biasv;
+        bstride = 2;
     } else if (biasv) {                                                // other widths: fold the biases into the weights once
         wmf_launch_bias_adjust(vals, indices, biasv, nnz, pl->w_eff, st);   // (w_eff: allocated by wmf_plan_create(bias = 1))
         vals = pl->w_eff;
@@ -772,7 +838,7 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
     const bool general_ok = f <= 144;
     if (pl->count[WMF_BIN_MFMA] > 0) {
         // one wave per row with the whole system in MFMA accumulator registers (wmf_directw.hip, wmf_directl.hip)
-        if (wmf_launch_directw(pl, V, biasv, indptr, indices, vals, f, ld, g, st)) return -1;
+        if (wmf_launch_directw(pl, V, side, indptr, indices, vals, f, ld, g, st)) return -1;
     }
     if (pl->count[WMF_BIN_GENERAL] > 0) {
         // f > 144: rows with more than 32 entries go to the workgroup-per-row kernel (wmf_wide.hip)

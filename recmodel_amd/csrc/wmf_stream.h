@@ -63,8 +63,11 @@ struct WmfRowStream {
 
     // request the factor rows of group g into ring slot S (compile time); fetch_meta(g) must have run,
     // and groups are requested in increasing order, so the metadata of g + 1 is fetched on the way out.
+    // side != NULL (split layout, wmf_internal.h; R >= 1): rows of V are ld floats of packed body, and the last dword block
+    // comes from the pairs: lane r = 0 gets the row's last feature, lanes r >= 1 its bias.
     template <int S>
-    __device__ __forceinline__ void load_group(int g, const float* __restrict__ V, int ld, int r, int q) {
+    __device__ __forceinline__ void load_group(int g, const float* __restrict__ V, int ld, int r, int q,
+                                               const float* __restrict__ side = nullptr) {
         const int nch = ld >> 2;
 #pragma unroll
         for (int t = 0; t < GS; ++t) {
@@ -80,7 +83,8 @@ struct WmfRowStream {
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) {
                 const int col = 64 * J + 16 * rr + r;
-                fr[S][t][4 * J + rr] = vrow[rr == R - 1 ? min(col, ld - 1) : col];
+                if (rr == R - 1 && side) fr[S][t][4 * J + rr] = side[2 * (int64_t)idxM[t] + min(r, 1)];
+                else fr[S][t][4 * J + rr] = vrow[rr == R - 1 ? min(col, ld - 1) : col];
             }
         }
         fetch_meta(g + 1, q);

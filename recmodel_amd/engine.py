@@ -71,6 +71,9 @@ class HipKernels:
     def ld_for(self, f):
         return int(self.lib.wmf_ld_for(f))
 
+    def whitened_row_floats(self, f, ld, bias):
+        return int(self.lib.wmf_whitened_row_floats(f, ld, int(bias)))
+
     def gram_workspace_bytes(self, f):
         return int(self.lib.wmf_gram_workspace_bytes(f))
 
@@ -349,9 +352,13 @@ class AlsEngine:
         # gathered factors of all ranks (chunk-major positions); with one rank the local block itself
         self.X = {s: (z(W * self.rpr[s], self.ld) if self.exchange else self.factors[s]) for s in self.n}
         self._pending = {s: [] for s in self.n}                            # all-gathers in flight
-        # whitened gathered factors / bias of the fixed side [W * rows_per_rank, ld]
-        self.V = {s: z(W * self.rpr[s], self.ld) for s in self.n}
-        self.bias_vec = {s: z(W * self.rpr[s]) for s in self.n}
+        # whitened gathered factors / bias of the fixed side [W * rows_per_rank, ld] -- or, where the library writes its
+        # split layout (include/wmf_hip.h, wmf_row_transform: k = 16 m with biases), a packed body [.., f - 1] and the
+        # {last feature, bias} pairs [.., 2]; either way row ranges of the two tensors are what the kernels are given
+        self.ldv = self.K.whitened_row_floats(self.f, self.ld, self.bias)
+        self.split = self.ldv != self.ld
+        self.V = {s: z(W * self.rpr[s], self.ldv) for s in self.n}
+        self.bias_vec = {s: (z(W * self.rpr[s], 2) if self.split else z(W * self.rpr[s])) for s in self.n}
         self.G = z(self.f * self.f, dtype=torch.float64)
         self.W_white, self.W_unwhite = z(self.f, self.ld), z(self.f, self.ld)
         self.info = z(4, dtype=torch.int32)
@@ -548,7 +555,7 @@ class AlsEngine:
         local_rows = torch.repeat_interleave(torch.arange(o.n_rows, device=self.device), o.indptr[1:] - o.indptr[:-1])
         indptr, idx, v = coo_to_csr(o.indices.to(torch.int64), local_rows, o.values, self.world * self.rpr[side])
         deg = (indptr[1:] - indptr[:-1]).to(torch.int32).contiguous()
-        w_eff = torch.empty_like(v) if self.bias else None
+        w_eff = torch.empty_like(v) if self.bias and not self.split else None    # (split layout: the kernels take the bias with the row)
         return indptr.contiguous(), deg, idx.contiguous(), v.contiguous(), w_eff
 
     def _shard(self, side, rows, cols, vals):
@@ -703,9 +710,9 @@ class AlsEngine:
         for c, (lo, ln) in enumerate(self.chunk_bounds[side]):
             r0, r1 = W * lo, W * (lo + ln)
             part = self.partial_all[side][r0:r1]
-            if self.bias and c == 0:                 # values - bias[indices] for ALL entries, once per half step
+            if self.bias and (c == 0 or self.split):  # values - bias[indices] for ALL entries, once per half step (split layout:
                 K.accumulate_rows(v_loc, b_loc, indptr[r0: r1 + 1], deg[r0:r1], idx, vals, r1 - r0, idx.numel(), self.f, self.ld,
-                                  part, w_eff)
+                                  part, w_eff)         # no such pass, the kernels take the bias with the gathered row)
             else:
                 K.accumulate_rows(v_loc, None, indptr[r0: r1 + 1], deg[r0:r1], idx, w_eff if self.bias else vals, r1 - r0,
                                   idx.numel(), self.f, self.ld, part, None)

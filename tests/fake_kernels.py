@@ -11,6 +11,21 @@ class NumpyKernels:
     def ld_for(self, f):
         return (f + 3) & ~3
 
+    def whitened_row_floats(self, f, ld, bias):
+        """The device library's split layout (include/wmf_hip.h, wmf_row_transform): packed body + {last feature, bias}
+        pairs for bias models at f = 16 m + 1 <= 144 (m + 1 not a multiple of 4), ld = f + 3."""
+        split = bias and 16 < f <= 144 and f % 16 == 1 and (f // 16) % 4 != 3 and ld == f + 3
+        return f - 1 if split else ld
+
+    def _whitened(self, V, bias_vec, f, ld):
+        """(rows x f whitened factors, bias or None) from either layout."""
+        if bias_vec is not None and self.whitened_row_floats(f, ld, True) == f - 1:
+            side = bias_vec.numpy().reshape(-1, 2).astype(np.float64)
+            body = V.numpy().reshape(-1, f - 1).astype(np.float64)
+            return np.concatenate([body, side[:, :1]], axis=1), side[:, 1]
+        v = V.numpy().astype(np.float64)[:, :f]
+        return v, (bias_vec.numpy().astype(np.float64) if bias_vec is not None else None)
+
     def gram_workspace_bytes(self, f):
         return 16
 
@@ -37,13 +52,21 @@ class NumpyKernels:
 
     def row_transform(self, inp, m, f, ld, W, set_col0_one, out, col0_out):
         x = inp.numpy()[:m, :f].astype(np.float64).copy()
+        split = set_col0_one and self.whitened_row_floats(f, ld, True) == f - 1
         if set_col0_one:
-            if col0_out is not None:
+            if split:
+                col0_out.numpy().reshape(-1, 2)[:m, 1] = inp.numpy()[:m, 0]
+            elif col0_out is not None:
                 col0_out.numpy()[:m] = inp.numpy()[:m, 0]
             x[:, 0] = 1.0
+        y = x @ W.numpy()[:, :f].astype(np.float64)
+        if split:
+            out.numpy().reshape(-1, f - 1)[:m] = y[:, : f - 1]
+            col0_out.numpy().reshape(-1, 2)[:m, 0] = y[:, f - 1]
+            return
         o = out.numpy()
         o[:m] = 0
-        o[:m, :f] = x @ W.numpy()[:, :f].astype(np.float64)
+        o[:m, :f] = y
 
     def plan_create(self, indptr_host, n, f, bias=False):
         deg = np.diff(indptr_host)
@@ -55,9 +78,8 @@ class NumpyKernels:
         pass
 
     def solve_rows(self, plan, V, bias_vec, indptr, indices, values, n, f, ld, g, fail):
-        v = V.numpy().astype(np.float64)
+        v, b = self._whitened(V, bias_vec, f, ld)
         ip, ix, w = indptr.numpy(), indices.numpy(), values.numpy().astype(np.float64)
-        b = bias_vec.numpy().astype(np.float64) if bias_vec is not None else None
         out = g.numpy()
         out[:n] = 0
         for u in range(n):
@@ -78,10 +100,11 @@ class NumpyKernels:
         ip = indptr.numpy()
         idx = indices.numpy()
         w = values.numpy().astype(np.float64)
-        if bias_vec is not None:
-            w = w - bias_vec.numpy()[idx]
-            w_eff.numpy()[:] = w
-        Vn = V.numpy()[:, :f].astype(np.float64)
+        Vn, b = self._whitened(V, bias_vec, f, ld)
+        if b is not None:
+            w = w - b[idx]
+            if w_eff is not None:
+                w_eff.numpy()[:] = w
         out = partial.numpy().reshape(-1, f * f + f)[slot_offset::slot_stride]
         assert (np.diff(ip) == degrees.numpy()).all()
         for i in range(n):

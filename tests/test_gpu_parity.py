@@ -467,7 +467,7 @@ def test_accumulate_then_eliminate_equals_the_row_solve(k, bias):
         torch.cumsum(cnt, 0, out=ptr[1:])
         idx, val = full.indices[m].contiguous(), full.values[m].contiguous()
         part = torch.full((700, pr), 7.0, device="cuda")
-        w_eff = torch.empty_like(val) if bias else None
+        w_eff = torch.empty_like(val) if bias and not eng.split else None    # (split layout: no bias pass, no workspace)
         K.accumulate_rows(eng.V["items"], eng.bias_vec["items"] if bias else None, ptr, cnt.to(torch.int32), idx, val, 700,
                           idx.numel(), f, ld, part, w_eff)
         total += part
@@ -506,19 +506,29 @@ def test_device_building_blocks_individually():
         Linv = np.linalg.inv(np.linalg.cholesky(G.cpu().numpy().reshape(f, f) + 0.1 * np.eye(f)))
         np.testing.assert_allclose(Wu.cpu().numpy()[:, :f], Linv, rtol=0, atol=1e-6 * np.abs(Linv).max())
         np.testing.assert_allclose(Ww.cpu().numpy()[:, :f], Linv.T, rtol=0, atol=1e-6 * np.abs(Linv).max())
+        Vref = Yt @ Linv.T
+        tol = 3e-6 * np.abs(Vref).max() * np.sqrt(f)
+        ldv = lib.wmf_whitened_row_floats(f, ld, bias)
+        assert ldv == (128 if (f, bias) == (129, 1) else ld)
+        if ldv != ld:
+            # f = 16 m + 1 <= 144 with biases: the SPLIT LAYOUT (include/wmf_hip.h, wmf_row_transform) -- a packed body of
+            # f - 1 floats per row and the pairs {feature f - 1, bias}; nothing is written behind either array
+            V = torch.full((m * ldv + 8,), 3.0, device="cuda")
+            bv = torch.full((2 * m + 8,), 5.0, device="cuda")
+            _lib.check(lib.wmf_row_transform(_ptr(Yd), m, f, ld, _ptr(Ww), bias, _ptr(V), _ptr(bv), _stream()))
+            Vn, bn = V.cpu().numpy(), bv.cpu().numpy()
+            np.testing.assert_allclose(Vn[: m * ldv].reshape(m, ldv), Vref[:, : f - 1], rtol=0, atol=tol)
+            np.testing.assert_allclose(bn[: 2 * m].reshape(m, 2)[:, 0], Vref[:, f - 1], rtol=0, atol=tol)
+            np.testing.assert_array_equal(bn[: 2 * m].reshape(m, 2)[:, 1], Y[:, 0])
+            assert np.all(Vn[m * ldv:] == 3.0) and np.all(bn[2 * m:] == 5.0)
+            with pytest.raises((ValueError, _lib.WmfLibraryError)):   # the pairs are not optional there
+                _lib.check(lib.wmf_row_transform(_ptr(Yd), m, f, ld, _ptr(Ww), bias, _ptr(V), None, _stream()))
+            continue
         V = torch.full((m, ld), 3.0, device="cuda")
         bv = torch.zeros(m, device="cuda")
         _lib.check(lib.wmf_row_transform(_ptr(Yd), m, f, ld, _ptr(Ww), bias, _ptr(V), _ptr(bv) if bias else None, _stream()))
-        Vref = Yt @ Linv.T
-        np.testing.assert_allclose(V.cpu().numpy()[:, :f], Vref, rtol=0, atol=3e-6 * np.abs(Vref).max() * np.sqrt(f))
-        pad = V.cpu().numpy()[:, f:]
-        if bias and f == 129:
-            # f = 16 m + 1 <= 144 with biases: the bias also rides in the row's first padding column (include/wmf_hip.h,
-            # wmf_row_transform), where the row kernels find it next to the border feature
-            np.testing.assert_array_equal(pad[:, 0], Y[:, 0])
-            assert np.all(pad[:, 1:] == 0)
-        else:
-            assert np.all(pad == 0)                        # (f = 257 is beyond those widths: a bias vector only)
+        np.testing.assert_allclose(V.cpu().numpy()[:, :f], Vref, rtol=0, atol=tol)
+        assert np.all(V.cpu().numpy()[:, f:] == 0)         # (f = 257 is beyond the split widths: a bias vector only)
         if bias:
             np.testing.assert_array_equal(bv.cpu().numpy(), Y[:, 0])
     # not positive definite -> info > 0, no exception inside the kernel, zero transforms
