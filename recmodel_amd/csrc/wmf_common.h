@@ -103,6 +103,17 @@ __device__ __forceinline__ float wmf_bcast_rowgroup(float v) {
     return __builtin_bit_cast(float, (KQ & 1) ? t[1] : t[0]);
 }
 
+// Sum of a value over the four 16-lane row groups, lane for lane, in every group: seven VALU instructions and no LDS round
+// trip (two ds_bpermute -- __shfl_xor 16, 32 -- cost a wave that runs alone on its SIMD some 200 exposed cycles).
+__device__ __forceinline__ float wmf_qsum(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    const auto s = __builtin_amdgcn_permlane32_swap(x, x, false, false);      // {g0 g1 g0 g1}, {g2 g3 g2 g3}
+    const float t = __builtin_bit_cast(float, (int)s[0]) + __builtin_bit_cast(float, (int)s[1]);   // {g0+g2, g1+g3, g0+g2, g1+g3}
+    const int y = __builtin_bit_cast(int, t);
+    const auto u = __builtin_amdgcn_permlane16_swap(y, y, false, false);      // {t0 t0 t0 t0}, {t1 t1 t1 t1}
+    return __builtin_bit_cast(float, (int)u[0]) + __builtin_bit_cast(float, (int)u[1]);
+}
+
 // In-place Gauss-Jordan inverse of a symmetric positive definite 16 x 16 tile held row-distributed:
 // lane (r, q) has A[r][4q + reg] in a[reg].  Step K: column K becomes e_K first, then every row gets
 // row_i += nf_i * row_K with nf = -A[i][K]/piv (rows i != K) or 1/piv - 1 (row K).
@@ -130,6 +141,57 @@ template <bool LDS = true, bool CHECK = true, int... Ks>
 __device__ __forceinline__ void gj_inv_sweep(f32x4& a, const int (&baddr)[4], int r, int q, bool& ok,
                                              std::integer_sequence<int, Ks...>) {
     (gj_inv_step<Ks, LDS, CHECK>(a, baddr, r, q, ok), ...);
+}
+
+// The same step for a wave that runs alone on its SIMD (the heavy-row kernels): every instruction costs issue time there,
+// so the lane masks are compile-time constants in scalar registers instead of compares (r == K: lanes K, K + 16, ..;
+// q == K / 4: one 16-lane group), and the multiplier is formed as  nf = (e_K - f) / piv,  e_K = [r == K]  -- which is
+// 1 / piv - 1 in the pivot row (f = piv there) and -f / piv elsewhere, the e_K doubling as the preset of column K.
+// 14 VALU instructions a step where the step above compiles to 19.  No pivot test: the caller checks the result.
+template <int K>
+__device__ __forceinline__ void gj_inv_step_lean(f32x4& a, int& pmin) {
+    constexpr int kq = K >> 2, kr = K & 3;
+    const float akr = a[kr];
+    const float piv = rlw(akr, K + 16 * kq);
+    // pivot test on the scalar unit: the smallest pivot BIT PATTERN as a signed integer -- for positive floats the integer
+    // order is the float order, a negative pivot is a negative integer -- which the caller compares with that of 1e-20f
+    // (WMF_PIVOT_MIN_BITS) once.  A NaN passes, and reaches the solution, which the caller tests.
+    pmin = min(pmin, __builtin_bit_cast(int, piv));
+    const float inv = __builtin_amdgcn_rcpf(piv);
+    const float fk = wmf_bcast_rowgroup<kq>(akr);
+    // (the masks are shifted into place next to their use: as C++ constants hipcc computes all twenty once, ahead of the
+    // eight sweeps of a row, and then spills them to VGPR lanes -- v_writelane / v_readlane around every use)
+    float eK, pre;
+    unsigned long long tmp;
+    asm volatile("s_lshl_b64 %2, %4, %5\n\t"
+                 "v_cndmask_b32 %0, 0, 1.0, %2\n\t"
+                 "s_lshl_b64 %2, 0xffff, %6\n\t"
+                 "v_cndmask_b32 %1, %3, %0, %2"
+                 : "=&v"(eK), "=v"(pre), "=&s"(tmp)
+                 : "v"(akr), "s"(0x0001000100010001ull), "n"(K), "n"(16 * kq));
+    a[kr] = pre;
+    const float nf = (eK - fk) * inv;
+    float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+    fmac_bcast4_self<K>(a0, a1, a2, a3, nf);
+    a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3;
+}
+template <int... Ks>
+__device__ __forceinline__ void gj_inv_sweep_lean(f32x4& a, int& pmin, std::integer_sequence<int, Ks...>) {
+    (gj_inv_step_lean<Ks>(a, pmin), ...);
+}
+#define WMF_PIVOT_MIN_BITS 0x1e3ce508
+
+// value of lane (r, r >> 2) -- the same lane position in row group r >> 2 -- on every lane (r, q); hi8 / hi4: the lane masks
+// r >= 8, (r & 4) != 0 as 64-bit constants
+__device__ __forceinline__ float wmf_fetch_own_group(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    const auto s = __builtin_amdgcn_permlane32_swap(x, x, false, false);      // {g0 g1 g0 g1}, {g2 g3 g2 g3}
+    int h;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(h) : "v"((int)s[0]), "v"((int)s[1]), "s"(0xFF00FF00FF00FF00ull));   // r >= 8: groups 2, 3
+    const auto t = __builtin_amdgcn_permlane16_swap(h, h, false, false);      // {lower group x 4}, {upper group x 4}
+    int o;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(o) : "v"((int)t[0]), "v"((int)t[1]), "s"(0xF0F0F0F0F0F0F0F0ull));   // r & 4: the upper one
+    return __builtin_bit_cast(float, o);
 }
 
 static inline int wmf_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

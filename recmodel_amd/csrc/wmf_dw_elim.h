@@ -52,6 +52,8 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
                                              int q, const int (&baddr)[4], int dbg, float (&gb)[NFB], float& tb, bool& ok,
                                              const float diag = 1.f) {
     float wvs[WREG ? NFB : 1][4], wbs[(WREG && BORDER) ? NFB : 1][4];
+    int pmin = 0x7f800000;                                       // wave-uniform: smallest pivot of the tile inverses (bit pattern)
+    float cacc2 = 0.f, eacc2 = 0.f;                              // BORDER: per-lane parts of the two border sums
     // ---- C: block elimination, everything in registers except the two panel buffers
     if (!WMF_ABL(dbg, 1)) {
 #pragma unroll
@@ -69,6 +71,11 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
             // brought back to unit scale for the sweep, and its inverse gets the factor once more -- it multiplies tiles
             // and vectors that still carry `diag`.
             if (diag != 1.f) X *= 1.f / diag;
+            if constexpr (!GJ_LDS) {                                 // (the kernels whose wave runs alone on its SIMD)
+                if (!WMF_ABL(dbg, 8)) gj_inv_sweep_lean(X, pmin, std::make_integer_sequence<int, 16>{});
+                if (diag != 1.f) X *= 1.f / diag;
+                return X;
+            }
 #if WMF_DW_OPAQUE
             // the sweep's lane masks (r == K, q == K / 4) are the same for every pivot; hipcc hoists all 36 of them out of
             // the pivot loop and then spills them to VGPR lanes (v_writelane / v_readlane pairs around every use).  Lane
@@ -90,8 +97,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
             // y_p[r] complete (its four q shares added), then w_p = X y_p: lane (r, q) has X[4q + reg][r] (X is
             // symmetric), so the products summed over the 16 lanes of a DPP row give w_p[4q + reg] on the whole row
             float yp = racc[p];
-            yp += __shfl_xor(yp, 16);
-            yp += __shfl_xor(yp, 32);
+            yp = wmf_qsum(yp);
             float wv0 = X[0] * yp, wv1 = X[1] * yp, wv2 = X[2] * yp, wv3 = X[3] * yp;
             wmf_row16_sum4(wv0, wv1, wv2, wv3);
             if constexpr (WREG) { wvs[p][0] = wv0; wvs[p][1] = wv1; wvs[p][2] = wv2; wvs[p][3] = wv3; }
@@ -99,16 +105,22 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
             float wb0 = 0.f, wb1 = 0.f, wb2 = 0.f, wb3 = 0.f;
             if constexpr (BORDER) {
                 float bp = bacc[p];
-                bp += __shfl_xor(bp, 16);
-                bp += __shfl_xor(bp, 32);
+                bp = wmf_qsum(bp);
                 wb0 = X[0] * bp; wb1 = X[1] * bp; wb2 = X[2] * bp; wb3 = X[3] * bp;
                 wmf_row16_sum4(wb0, wb1, wb2, wb3);
                 if constexpr (WREG) { wbs[p][0] = wb0; wbs[p][1] = wb1; wbs[p][2] = wb2; wbs[p][3] = wb3; }
                 else if (r == 0) *reinterpret_cast<float4*>(&Wb[16 * p + 4 * q]) = make_float4(wb0, wb1, wb2, wb3);
-                // b_p^T w^b_p and b_p^T w^y_p: this q group's rows 4q + reg (b_p[row] sits in lane `row`)
-                const float b0 = __shfl(bp, 4 * q), b1 = __shfl(bp, 4 * q + 1), b2 = __shfl(bp, 4 * q + 2), b3 = __shfl(bp, 4 * q + 3);
-                cacc -= b0 * wb0 + b1 * wb1 + b2 * wb2 + b3 * wb3;
-                eacc -= b0 * wv0 + b1 * wv1 + b2 * wv2 + b3 * wv3;
+                // b_p^T w^b_p and b_p^T w^y_p without moving anything: b_p[row] sits in lane r = row of every group and
+                // w_p[4q + reg] on every lane of group q, so the lanes with r >> 2 == q hold one product each (reg = r & 3);
+                // summed over the wave at the end
+                {
+                    const int sel = r & 3;
+                    const float wbs_ = sel == 0 ? wb0 : sel == 1 ? wb1 : sel == 2 ? wb2 : wb3;
+                    const float wvs_ = sel == 0 ? wv0 : sel == 1 ? wv1 : sel == 2 ? wv2 : wv3;
+                    const float bm = (r >> 2) == q ? bp : 0.f;
+                    cacc2 -= bm * wbs_;
+                    eacc2 -= bm * wvs_;
+                }
             }
             if constexpr (F16T) {
                 // Row p in split f16 (header comment): W'_pj = -X B_pj replaces the tile (the sign makes the trailing update
@@ -190,8 +202,8 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
     // ---- D: g_p = w_p - sum_{j > p} W_pj g_j ; gb[j] = g_j[lane & 15] on every lane
     tb = 0.f;                                                // BORDER: the last unknown
     if constexpr (BORDER) {
-        cacc += __shfl_xor(cacc, 16); cacc += __shfl_xor(cacc, 32);
-        eacc += __shfl_xor(eacc, 16); eacc += __shfl_xor(eacc, 32);
+        cacc = wmf_qsum(cacc + wmf_row16_sum(cacc2));
+        eacc = wmf_qsum(eacc + wmf_row16_sum(eacc2));
         const float piv = diag + cacc;                      // identity + c - sum_p b_p^T w^b_p
         if (!(piv > 1e-20f)) ok = false;
         tb = eacc * __builtin_amdgcn_rcpf(piv);
@@ -206,16 +218,25 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) s[reg] += (F16T ? -acc[t][reg] : acc[t][reg]) * gb[j];      // (F16T: the tile holds -W_pj)
             }
+            if (p + 1 < NFB) wmf_row16_sum4(s[0], s[1], s[2], s[3]);
             float gsel = 0.f;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 float w;                                                              // w_p[4q + reg]
                 if constexpr (WREG) { w = wvs[p][reg]; if constexpr (BORDER) w -= tb * wbs[p][reg]; }
                 else { w = Wv[16 * p + 4 * q + reg]; if constexpr (BORDER) w -= tb * Wb[16 * p + 4 * q + reg]; }
-                const float gv = w - ((p + 1 < NFB) ? wmf_row16_sum(s[reg]) : 0.f);  // g_p[4q + reg] on every lane (., q)
+                const float gv = w - s[reg];                                         // g_p[4q + reg] on every lane (., q)
                 gsel = ((r & 3) == reg) ? gv : gsel;
             }
-            gb[p] = __shfl(gsel, 16 * (r >> 2) + (r & 3)); // g_p[r] sits in q-group r >> 2, in a lane whose r & 3 matches
+            gb[p] = wmf_fetch_own_group(gsel);             // g_p[r] sits in q-group r >> 2, in the lanes whose r & 3 matches
         }
+    }
+    if constexpr (!GJ_LDS) {
+        // the lean sweep's pivot test lets a NaN through (wmf_common.h): it is in the solution now
+        bool bad = !(pmin > WMF_PIVOT_MIN_BITS);
+#pragma unroll
+        for (int p = 0; p < NFB; ++p) bad |= !(fabsf(gb[p]) < 3.0e38f);
+        if constexpr (BORDER) bad |= !(fabsf(tb) < 3.0e38f);
+        if (__any(bad)) ok = false;
     }
 }

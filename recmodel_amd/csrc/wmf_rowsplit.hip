@@ -423,8 +423,7 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
                 f32x4 X = acc[b0];
                 gj_inv_sweep(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
                 float yp = yacc[S];
-                yp += __shfl_xor(yp, 16);
-                yp += __shfl_xor(yp, 32);
+                yp = wmf_qsum(yp);
                 float wv0 = X[0] * yp, wv1 = X[1] * yp, wv2 = X[2] * yp, wv3 = X[3] * yp;
                 wmf_row16_sum4(wv0, wv1, wv2, wv3);              // w_p[4q + reg] on the whole 16-lane row
                 if (r == 0) {
@@ -433,8 +432,7 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
                 }
                 if constexpr (BORDER) {                          // the border column rides along like a second right-hand side
                     float bp = bacc[S];
-                    bp += __shfl_xor(bp, 16);
-                    bp += __shfl_xor(bp, 32);
+                    bp = wmf_qsum(bp);
                     float wb0 = X[0] * bp, wb1 = X[1] * bp, wb2 = X[2] * bp, wb3 = X[3] * bp;
                     wmf_row16_sum4(wb0, wb1, wb2, wb3);
                     if (r == 0) {
@@ -444,8 +442,8 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
                     const float b0v = __shfl(bp, 4 * q), b1v = __shfl(bp, 4 * q + 1), b2v = __shfl(bp, 4 * q + 2), b3v = __shfl(bp, 4 * q + 3);
                     float cc = b0v * wb0 + b1v * wb1 + b2v * wb2 + b3v * wb3;      // this q group's rows of b_p^T w^b_p
                     float ec = b0v * wv0 + b1v * wv1 + b2v * wv2 + b3v * wv3;
-                    cc += __shfl_xor(cc, 16); cc += __shfl_xor(cc, 32);
-                    ec += __shfl_xor(ec, 16); ec += __shfl_xor(ec, 32);
+                    cc = wmf_qsum(cc);
+                    ec = wmf_qsum(ec);
                     if (lane == 0) { bsc[0] += cc; bsc[1] += ec; }   // one pivot owner at a time, barriers in between
                 }
                 if constexpr (F16A) {
@@ -541,8 +539,8 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
             }
             float tb = 0.f;                                      // BORDER: the last unknown
             if constexpr (BORDER) {
-                cacc += __shfl_xor(cacc, 16); cacc += __shfl_xor(cacc, 32);
-                eacc += __shfl_xor(eacc, 16); eacc += __shfl_xor(eacc, 32);
+                cacc = wmf_qsum(cacc);
+                eacc = wmf_qsum(eacc);
                 const float piv = 1.f + cacc - bsc[0];           // identity + c - sum_p b_p^T w^b_p (the last pivot's barrier made bsc final)
                 if (!(piv > 1e-20f)) ok = false;
                 tb = (eacc - bsc[1]) * __builtin_amdgcn_rcpf(piv);
@@ -603,6 +601,9 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
 #ifndef RS_OCC16
 #define RS_OCC16 2
 #endif
+// (The same kernel at NFB = 8 -- k = 128, nine tiles per wave, four workgroups per CU -- was measured against the one-wave-
+// per-row LDS-DMA kernel on cfg3's item side: 119.7 ms against 22.5 ms, same rows to 3e-7.  The four-wave split pays a
+// workgroup barrier and an LDS round trip per pivot tile and per 32 entries; it is what makes f > 144 fit, not a fast path.)
 template <int NFB, bool BORDER, bool F16A, int MODE>
 __global__ __launch_bounds__(256, F16A ? RS_OCC16 : 2) void solve_rowsplit_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                                 const float* __restrict__ V, const float* __restrict__ biasv,
@@ -640,8 +641,8 @@ static void launch_rowsplit_f(const int32_t* rows, int64_t count, const float* V
     static const char* nm = wmf_kname("solve_rowsplit_kernel<%d, %s, %s, %d>", NFB, BORDER ? "true" : "false",
                                       F16A ? "true" : "false", MODE);
     WMF_LAUNCH(nm, (solve_rowsplit_kernel<NFB, BORDER, F16A, MODE>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, rows, count, V,
-               biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, wmf_debug_flags, pl->seg_lo, pl->seg_d,
-               pl->seg_first, pl->partial);
+               biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count,
+               wmf_debug_flags, pl->seg_lo, pl->seg_d, pl->seg_first, pl->partial);
 }
 
 template <int NFB, bool BORDER>

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
             for (int reg = 0; reg < 4; ++reg)
                 out[reg] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(caddr[reg], __builtin_bit_cast(int, v)));
         };
-        auto qsum = [&](float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };
+        auto qsum = [&](float v) { return wmf_qsum(v); };
         float eA[4], eB[4], pA[4], pB[4];
         col4(e0, eA);
         col4(e1, eB);

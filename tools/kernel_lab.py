@@ -40,4 +40,10 @@ for fl in flags:
     lib.wmf_profile_enable(0)
     print(f"flags={fl}: " + ", ".join(f"{nm}={ms / reps:.3f}ms/{n // reps}" for nm, _, ms, n, _, _ in _lib.profile_table(lib)))
     lib.wmf_profile_reset()
+    gnow = eng.g[side].clone()
+    if fl == flags[0]:
+        gref = gnow
+    else:                                # kernel selections must agree (ablations will not)
+        err = (gnow - gref).norm(dim=1) / gref.norm(dim=1).clamp_min(1e-30)
+        print(f"    vs flags={flags[0]}: worst row {float(err.max()):.2e}, fro {float((gnow - gref).norm() / gref.norm()):.2e}, fails {int(eng.fail[0])}")
 lib.wmf_debug_set_flags(0)
