@@ -177,6 +177,17 @@ int wmf_hit_counts(const float* users, const float* items, int f, int ld, int bi
 int wmf_spmm_rows(const float* V, const int64_t* indptr, const int32_t* indices, const float* values,
                   int64_t n, int f, int ld, float* g, void* stream);
 
+/* COO -> CSR on the device, stable in (row, column): entry e = (rows[e], cols[e], values[e]), all device arrays.  With
+ * (rows, cols) swapped this is the transpose the reference takes before training (wmf_model.py:128, count_mat.T.tocsr());
+ * the sharded engine also builds every rank's shards with it.  Duplicates are kept, in their stored order.
+ * indptr_out int64[n_rows + 1], indices_out int32[nnz], values_out float[nnz]; n_cols <= 2^31 - 1, n_rows * n_cols < 2^63,
+ * nnz < 2^32.  bad_flag (device int32, caller zeroes): set to 1 if an entry lies outside [0, n_rows) x [0, n_cols) -- the
+ * outputs are then unspecified (never written out of bounds).  workspace: wmf_coo_to_csr_workspace_bytes() bytes. */
+int64_t wmf_coo_to_csr_workspace_bytes(int64_t nnz, int64_t n_rows, int64_t n_cols);
+int wmf_coo_to_csr(const int64_t* rows, const int64_t* cols, const float* values, int64_t nnz, int64_t n_rows, int64_t n_cols,
+                   int64_t* indptr_out, int32_t* indices_out, float* values_out, int32_t* bad_flag, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
 /* values[i] = alpha*log(1+beta*values[i]) (mode 0) or alpha*values[i] (mode 1), in place on the
  * device.  wmf_model.py:119-123. */
 int wmf_confidence_transform(float* values, int64_t nnz, double alpha, double beta, int mode, void* stream);

@@ -458,6 +458,26 @@ int wmf_spmm_rows(const float* V, const int64_t* indptr, const int32_t* indices,
     return check_launch("wmf_spmm_rows");
 }
 
+int64_t wmf_coo_to_csr_workspace_bytes(int64_t nnz, int64_t n_rows, int64_t n_cols) {
+    if (nnz < 0 || n_rows < 0 || n_cols < 1) return 0;
+    return wmf_csr_ws_bytes(nnz, n_rows, n_cols);
+}
+
+int wmf_coo_to_csr(const int64_t* rows, const int64_t* cols, const float* values, int64_t nnz, int64_t n_rows, int64_t n_cols,
+                   int64_t* indptr_out, int32_t* indices_out, float* values_out, int32_t* bad_flag, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+    if (nnz < 0 || n_rows < 0 || n_cols < 1 || n_cols > 0x7fffffffLL || !indptr_out || !bad_flag ||
+        (nnz > 0 && (!rows || !cols || !values || !indices_out || !values_out || !workspace))) {
+        wmf_set_error("wmf_coo_to_csr: null pointer or bad size"); return WMF_EINVAL;
+    }
+    const int rc = wmf_launch_coo_to_csr(rows, cols, values, nnz, n_rows, n_cols, indptr_out, indices_out, values_out, bad_flag,
+                                         workspace, workspace_bytes, (hipStream_t)stream);
+    if (rc == -3) { wmf_set_error("wmf_coo_to_csr: workspace too small (need %lld bytes)", (long long)wmf_csr_ws_bytes(nnz, n_rows, n_cols)); return WMF_EINVAL; }
+    if (rc == -4) { wmf_set_error("wmf_coo_to_csr: n_rows * n_cols must fit 63 bits and nnz 32"); return WMF_EINVAL; }
+    if (rc) { wmf_set_error("wmf_coo_to_csr: sort failed"); return WMF_EHIP; }
+    return check_launch("wmf_coo_to_csr");
+}
+
 int wmf_confidence_transform(float* values, int64_t nnz, double alpha, double beta, int mode, void* stream) {
     if ((!values && nnz > 0) || nnz < 0 || (mode != 0 && mode != 1)) { wmf_set_error("wmf_confidence_transform: bad arguments"); return WMF_EINVAL; }
     wmf_launch_confidence(values, nnz, alpha, beta, mode, (hipStream_t)stream);

@@ -75,6 +75,11 @@ int wmf_launch_eliminate(float* partial, int64_t n, int slots_per_row, int f, in
                          int32_t* fail_count, hipStream_t st);
 void wmf_launch_bias_adjust(const float* vals, const int32_t* indices, const float* biasv, int64_t nnz, float* w_eff,
                             hipStream_t st);
+// wmf_csr.hip: COO -> CSR, stable in (row, column)
+int64_t wmf_csr_ws_bytes(int64_t nnz, int64_t n_rows, int64_t n_cols);
+int wmf_launch_coo_to_csr(const int64_t* rows, const int64_t* cols, const float* vals, int64_t nnz, int64_t n_rows, int64_t n_cols,
+                          int64_t* indptr, int32_t* indices, float* values, int32_t* bad_flag, void* ws, int64_t ws_bytes,
+                          hipStream_t st);
 int wmf_wide_supported(int f);
 int wmf_launch_wide(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                     const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,

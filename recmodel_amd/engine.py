@@ -124,6 +124,21 @@ class HipKernels:
         _lib.check(self.lib.wmf_eval_sqerr(_ptr(users), _ptr(items), f, ld, int(bias), _ptr(indptr), _ptr(indices),
                                            _ptr(values), n, _ptr(out3), _ptr(ws), _stream()))
 
+    def coo_to_csr(self, rows, cols, vals, n_rows, n_cols):
+        """(indptr int64, indices int32, values) of the entries sorted stably by (row, column): wmf_coo_to_csr."""
+        nnz = rows.numel()
+        dev = rows.device
+        indptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
+        indices = torch.empty(nnz, dtype=torch.int32, device=dev)
+        values = torch.empty(nnz, dtype=torch.float32, device=dev)
+        bad = torch.zeros(4, dtype=torch.int32, device=dev)
+        ws = torch.empty(int(self.lib.wmf_coo_to_csr_workspace_bytes(nnz, n_rows, n_cols)), dtype=torch.uint8, device=dev)
+        _lib.check(self.lib.wmf_coo_to_csr(_ptr(rows), _ptr(cols), _ptr(vals), nnz, n_rows, n_cols, _ptr(indptr), _ptr(indices),
+                                           _ptr(values), _ptr(bad), _ptr(ws), ws.numel(), _stream()))
+        if int(bad[0]):
+            raise IndexError(f"an entry lies outside the {n_rows} x {n_cols} matrix")
+        return indptr, indices, values
+
     def confidence_transform(self, values, alpha, beta, mode):
         _lib.check(self.lib.wmf_confidence_transform(_ptr(values), values.numel(), float(alpha), float(beta), int(mode),
                                                      _stream()))
@@ -156,8 +171,15 @@ class Csr:
                 pass
 
 
-def coo_to_csr(rows, cols, vals, n_rows):
-    """Sort COO entries by (row, col) on the device and build indptr.  Stable: duplicates survive."""
+def coo_to_csr(rows, cols, vals, n_rows, kernels=None, n_cols=None):
+    """Sort COO entries by (row, col) and build indptr.  Stable: duplicates survive.  On the device this is the library's
+    wmf_coo_to_csr (kernels = HipKernels); the torch formulation below serves the CPU rehearsal of the host logic
+    (tests/fake_kernels.py has no such method)."""
+    if kernels is not None and hasattr(kernels, "coo_to_csr"):
+        if n_cols is None:
+            n_cols = int(cols.max().item()) + 1 if cols.numel() else 1
+        return kernels.coo_to_csr(rows.to(torch.int64).contiguous(), cols.to(torch.int64).contiguous(),
+                                  vals.to(torch.float32).contiguous(), int(n_rows), int(n_cols))
     n_cols_bound = int(cols.max().item()) + 1 if cols.numel() else 1
     key = rows.to(torch.int64) * n_cols_bound + cols.to(torch.int64)
     order = torch.argsort(key, stable=True)
@@ -553,7 +575,7 @@ class AlsEngine:
         of ``side``.  Returns (indptr, degrees int32, indices int32, values, w_eff workspace)."""
         o = self.csr[self._other(side)]
         local_rows = torch.repeat_interleave(torch.arange(o.n_rows, device=self.device), o.indptr[1:] - o.indptr[:-1])
-        indptr, idx, v = coo_to_csr(o.indices.to(torch.int64), local_rows, o.values, self.world * self.rpr[side])
+        indptr, idx, v = coo_to_csr(o.indices.to(torch.int64), local_rows, o.values, self.world * self.rpr[side], self.K, o.n_rows)
         deg = (indptr[1:] - indptr[:-1]).to(torch.int32).contiguous()
         w_eff = torch.empty_like(v) if self.bias and not self.split else None    # (split layout: the kernels take the bias with the row)
         return indptr.contiguous(), deg, idx.contiguous(), v.contiguous(), w_eff
@@ -562,7 +584,7 @@ class AlsEngine:
         """CSR of this rank's rows of ``side`` (all of them its own already): local row x gathered position of the column."""
         other = self._other(side)
         local = self.shard[side].local_of(rows)
-        indptr, idx, v = coo_to_csr(local, self.positions(other, cols), vals, self.rpr[side])
+        indptr, idx, v = coo_to_csr(local, self.positions(other, cols), vals, self.rpr[side], self.K, self.world * self.rpr[other])
         return Csr(self.K, indptr, idx, v, self.world * self.rpr[other], self.f, self.bias)
 
     def set_factors(self, side, full):
