@@ -142,10 +142,12 @@ int wmf_predict_pairs(const float* users, const float* items, int f, int ld, int
                       float* out, void* stream);
 
 /* WMF.rank, wmf_model.py:25-47: scores of ONE user (*user_idx, device) against n_cand candidate item rows
- * (cand_idx, device), sorted by score, best first.  out_pos[k] = position in cand_idx of the k-th best
+ * (cand_idx, device), the topn best sorted by score, best first.  out_pos[k] = position in cand_idx of the k-th best
  * candidate (the reference returns items[order]); ties keep candidate order (the reference's tie order is
  * whatever argpartition / argsort leave).  out_scores may be NULL.  1 <= topn <= n_cand.
- * workspace: wmf_rank_workspace_bytes(n_cand) bytes of device memory. */
+ * A top-n select like the reference's argpartition (:40-43), not a sort of all candidates: only the candidates of the
+ * score-histogram bins that reach down to the topn-th best are sorted.  The length of that list is read back, so this
+ * call SYNCHRONISES its stream.  workspace: wmf_rank_workspace_bytes(n_cand) bytes of device memory. */
 int64_t wmf_rank_workspace_bytes(int64_t n_cand);
 int wmf_rank_topn(const float* users, const float* items, int f, int ld, int bias, const int32_t* user_idx,
                   const int32_t* cand_idx, int64_t n_cand, int64_t topn, int32_t* out_pos, float* out_scores,

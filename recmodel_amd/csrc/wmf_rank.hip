@@ -5,9 +5,10 @@
 //                     than n candidates score higher, so one wave per test entry scores the candidates (16 lanes
 //                     per candidate, four at a time) and counts; hits are integer atomics, hence deterministic.
 //                     The random draws stay on the host, in the reference's np.random call order.
-//   * rank         -- WMF.rank (RecModel/wmf_model.py:25-47): scores of one user against a candidate list, then a
-//                     stable descending radix sort of (score, position) pairs (rocPRIM's device sort: the ordering
-//                     is not the hot path; the scores are the same predict kernel as eval_prec).
+//   * rank         -- WMF.rank (RecModel/wmf_model.py:25-47): scores of one user against a candidate list (the same
+//                     predict kernel as eval_prec), then a top-n SELECT -- histogram, threshold bin, compaction -- and a
+//                     sort of the short list that survives it (rocPRIM's device sort, on a few thousandths of the
+//                     candidates); the batched form (many users) sorts its score matrix by segments.
 #include <cstring>            // rocprim/iterator/texture_cache_iterator.hpp uses memset without including it
 
 #include <rocprim/rocprim.hpp>
@@ -170,18 +171,75 @@ int wmf_launch_hits(const float* users, const float* items, int ld, int bias, co
     return 0;
 }
 
-// workspace: [scores n][sorted scores n][positions n][sorted positions n][rocPRIM temporary]
+// ---- rank of one user: top-n SELECT, as the reference's np.argpartition + argsort of the n best (wmf_model.py:40-43),
+// not a sort of the whole candidate list.  Scores become order-preserving 32-bit keys; a 4096-bin histogram of their top
+// 12 bits finds the bin T that holds the n-th best; every candidate in a bin >= T -- the n best and the rest of bin T, a
+// few thousandths of the list unless the scores pile up -- is compacted as a 64-bit key (score key, ~position) and only
+// that short list is sorted (descending: equal scores come out in candidate order, so the result is deterministic although
+// the compaction order is not).  One 8-byte read-back tells the host how long the list is: the call synchronises its stream.
+__device__ __forceinline__ uint32_t rank_key(float s) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);           // ascending in the float order
+}
+
+__global__ __launch_bounds__(256) void rank_hist_kernel(const float* __restrict__ scores, int64_t n, uint32_t* __restrict__ bins) {
+    __shared__ uint32_t h[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) h[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) atomicAdd(&h[rank_key(scores[i]) >> 20], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256) if (h[i]) atomicAdd(&bins[i], h[i]);
+}
+
+// ctrl[0] = T: the highest bin such that bins T .. 4095 hold at least topn candidates; ctrl[1] = the compaction counter
+__global__ __launch_bounds__(256) void rank_pick_kernel(const uint32_t* __restrict__ bins, int64_t topn, uint32_t* __restrict__ ctrl) {
+    __shared__ uint32_t part[256];
+    const int t = threadIdx.x;                                   // thread t owns bins 16 t .. 16 t + 15
+    uint32_t s = 0;
+    for (int i = 0; i < 16; ++i) s += bins[16 * t + i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t acc = 0;
+        int g = 255;
+        for (; g > 0 && acc + part[g] < (uint64_t)topn; --g) acc += part[g];
+        int b = 16 * g + 15;
+        for (; b > 16 * g && acc + bins[b] < (uint64_t)topn; --b) acc += bins[b];
+        ctrl[0] = (uint32_t)b;
+        ctrl[1] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void rank_compact_kernel(const float* __restrict__ scores, int64_t n, uint32_t* __restrict__ ctrl,
+                                                           unsigned long long* __restrict__ keys) {
+    const uint32_t T = ctrl[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t k = rank_key(scores[i]);
+        if ((k >> 20) >= T) keys[atomicAdd(&ctrl[1], 1u)] = ((unsigned long long)k << 32) | (0xFFFFFFFFu - (uint32_t)i);
+    }
+}
+
+__global__ void rank_take_kernel(const unsigned long long* __restrict__ skeys, const float* __restrict__ scores, int64_t topn,
+                                 int32_t* __restrict__ out_pos, float* __restrict__ out_scores) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < topn; k += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t pos = 0xFFFFFFFFu - (uint32_t)(skeys[k] & 0xFFFFFFFFull);
+        out_pos[k] = (int32_t)pos;
+        if (out_scores) out_scores[k] = scores[pos];
+    }
+}
+
+// workspace: [scores n][keys n x 8][sorted keys n x 8][bins 4096 + ctrl][rocPRIM temporary]
 static size_t rank_sort_temp_bytes(int64_t n) {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs_desc(nullptr, bytes, (float*)nullptr, (float*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
-                                         (size_t)n, 0, 32, (hipStream_t)0);
+    (void)rocprim::radix_sort_keys_desc(nullptr, bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)n, 0, 64,
+                                        (hipStream_t)0);
     return bytes;
 }
 
 int64_t wmf_rank_ws_bytes(int64_t n) {
     if (n <= 0) return 256;
     const size_t arr = (((size_t)n * 4 + 255) / 256) * 256;
-    return (int64_t)(4 * arr + rank_sort_temp_bytes(n) + 256);
+    return (int64_t)(5 * arr + 4096 * 4 + 256 + rank_sort_temp_bytes(n) + 256);
 }
 
 int wmf_launch_rank(const float* users, const float* items, int f, int ld, int bias, const int32_t* user_idx,
@@ -192,17 +250,28 @@ int wmf_launch_rank(const float* users, const float* items, int f, int ld, int b
     const size_t arr = (((size_t)n * 4 + 255) / 256) * 256;
     char* base = static_cast<char*>(ws);
     float* scores = reinterpret_cast<float*>(base);
-    float* sorted = reinterpret_cast<float*>(base + arr);
-    int32_t* pos = reinterpret_cast<int32_t*>(base + 2 * arr);
-    int32_t* spos = reinterpret_cast<int32_t*>(base + 3 * arr);
-    void* temp = base + 4 * arr;
-    size_t temp_bytes = rank_sort_temp_bytes(n);
+    auto* keys = reinterpret_cast<unsigned long long*>(base + arr);
+    auto* skeys = reinterpret_cast<unsigned long long*>(base + 3 * arr);
+    uint32_t* bins = reinterpret_cast<uint32_t*>(base + 5 * arr);
+    uint32_t* ctrl = bins + 4096;
+    void* temp = base + 5 * arr + 4096 * 4 + 256;
     if (wmf_launch_predict(users, items, f, ld, bias, user_idx, 1, cand, n, scores, st)) return -1;
+    if (hipMemsetAsync(bins, 0, 4096 * 4 + 256, st) != hipSuccess) return -2;
     int64_t grid = (n + 255) / 256;
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)grid), dim3(256), 0, st, pos, n);
-    if (rocprim::radix_sort_pairs_desc(temp, temp_bytes, scores, sorted, pos, spos, (size_t)n, 0, 32, st) != hipSuccess) return -2;
-    if (hipMemcpyAsync(out_pos, spos, (size_t)topn * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return -2;
-    if (out_scores && hipMemcpyAsync(out_scores, sorted, (size_t)topn * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return -2;
+    if (grid > 2048) grid = 2048;
+    WMF_LAUNCH("rank_hist_kernel", rank_hist_kernel, dim3((unsigned)grid), dim3(256), 0, st, scores, n, bins);
+    WMF_LAUNCH("rank_pick_kernel", rank_pick_kernel, dim3(1), dim3(256), 0, st, bins, topn, ctrl);
+    WMF_LAUNCH("rank_compact_kernel", rank_compact_kernel, dim3((unsigned)grid), dim3(256), 0, st, scores, n, ctrl, keys);
+    uint32_t host_ctrl[2] = {0, 0};
+    if (hipMemcpyAsync(host_ctrl, ctrl, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
+    const size_t m = host_ctrl[1];
+    if ((int64_t)m < topn || (int64_t)m > n) return -2;
+    size_t temp_bytes = rank_sort_temp_bytes(n);
+    {
+        WmfProfScope ps("rocprim::radix_sort_keys_desc (rank)", st);
+        if (rocprim::radix_sort_keys_desc(temp, temp_bytes, keys, skeys, m, 0, 64, st) != hipSuccess) return -2;
+    }
+    hipLaunchKernelGGL(rank_take_kernel, dim3((unsigned)((topn + 255) / 256 > 1024 ? 1024 : (topn + 255) / 256)), dim3(256), 0, st,
+                       skeys, scores, topn, out_pos, out_scores);
     return 0;
 }

@@ -166,6 +166,31 @@ def test_rank_full_catalogue_on_device():
         m.rank(np.array([0, n_items]), 3, topn=1)
 
 
+def test_rank_select_with_ties_and_extremes():
+    """The top-n select of wmf_rank_topn where its histogram cannot separate the candidates: every score equal (the list
+    that is sorted is the whole list; ties come out in candidate order), two score levels with the cut inside the lower
+    one, infinities, and topn = 1 / n_cand."""
+    from recmodel_amd import WMF
+    n_items, k = 30_000, 8
+    m = WMF(num_items=n_items, num_users=2, dim=k, gamma=0.1, weighted=True, bias=False)
+    m.users = np.zeros((2, k), dtype=np.float32); m.users[0, 0] = 1.0
+    m.items = np.zeros((n_items, k), dtype=np.float32)
+    cand = np.arange(n_items)[::-1].copy()                               # candidate order != item order
+    got = m.rank(cand, 0, topn=7)                                        # all scores 0
+    np.testing.assert_array_equal(got, cand[:7])
+    m.items[::3, 0] = 2.0                                                # 10 000 items score 2, the others 0
+    m.items = m.items.copy()
+    hi = [i for i in cand if i % 3 == 0]
+    lo = [i for i in cand if i % 3 != 0]
+    np.testing.assert_array_equal(m.rank(cand, 0, topn=10_003), np.array(hi + lo[:3]))
+    np.testing.assert_array_equal(m.rank(cand, 0, topn=1), np.array(hi[:1]))
+    np.testing.assert_array_equal(m.rank(cand, 0, topn=n_items), np.array(hi + lo))
+    m.items[5, 0], m.items[6, 0] = np.inf, -np.inf
+    m.items = m.items.copy()
+    r = m.rank(cand, 0, topn=n_items)
+    assert r[0] == 5 and r[-1] == 6
+
+
 def test_unweighted_branch_matches_reference_golden(WMF):
     g = load_golden("train_unweighted.npz")
     util = csr_from(g, "util")
