@@ -160,15 +160,17 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
         }
     };
     // the 16 rows of group gi (S = gi % 4 = its ring slot and its position in the block) -> 8 DMA instructions
-    auto issue_rows = [&](auto slot, int gi, int base) {
-        constexpr int S = decltype(slot)::value;
-        const unsigned par = ((base + (gi >> 2)) & 3) * 256;
+    // (S = gi % 4, the group's ring slot and its position in its block: a run-time value, so that the chunk loop below is
+    // ONE loop body -- with the slot as a template constant the two unrolled bodies got different register assignments for
+    // the accumulators and hipcc moved ~170 of them between AGPRs and VGPRs on every trip)
+    auto issue_rows = [&](int S, int gi, int base) {
+        const unsigned par = ((base + (gi >> 2)) & 3) * 256 + S * 64;
         // this lane's rows: entries EPI i + h of the group, i = 0 .. NI - 1
-        f32x2 i0 = dl_read2<S * 16, S * 16 + EPI>(idx8_rd + par), i1 = dl_read2<S * 16 + 2 * EPI, S * 16 + 3 * EPI>(idx8_rd + par);
+        f32x2 i0 = dl_read2<0, EPI>(idx8_rd + par), i1 = dl_read2<2 * EPI, 3 * EPI>(idx8_rd + par);
         f32x2 i2 = f32x2{0.f, 0.f}, i3 = f32x2{0.f, 0.f};       // (not copies of i0: it is still in flight)
         if constexpr (NI == 8) {
-            i2 = dl_read2<S * 16 + 4 * EPI, S * 16 + 5 * EPI>(idx8_rd + par);
-            i3 = dl_read2<S * 16 + 6 * EPI, S * 16 + 7 * EPI>(idx8_rd + par);
+            i2 = dl_read2<4 * EPI, 5 * EPI>(idx8_rd + par);
+            i3 = dl_read2<6 * EPI, 7 * EPI>(idx8_rd + par);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3)::"memory");
         const float ids[8] = {i0[0], i0[1], i1[0], i1[1], i2[0], i2[1], i3[0], i3[1]};
@@ -190,10 +192,10 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
         dl_wait_vm<0>();
         issue_border(0, base);
         if (d_ > 64) issue_meta(1, lo_, d_, base);
-        issue_rows(std::integral_constant<int, 0>{}, 0, base);
-        if (ng > 1) issue_rows(std::integral_constant<int, 1>{}, 1, base);
-        if (ng > 2) issue_rows(std::integral_constant<int, 2>{}, 2, base);
-        if constexpr (X6) { if (ng > 3) issue_rows(std::integral_constant<int, 3>{}, 3, base); }     // two whole chunks
+        issue_rows(0, 0, base);
+        if (ng > 1) issue_rows(1, 1, base);
+        if (ng > 2) issue_rows(2, 2, base);
+        if constexpr (X6) { if (ng > 3) issue_rows(3, 3, base); }     // two whole chunks
     };
     int mb = 0;                                         // metadata buffer of the current row's block 0
     if (it < count) { item(it, u, lo, d); prime(lo, d, mb, false); }
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
                     issue_border(gn >> 2, mb);
                     if (64 * ((gn >> 2) + 1) < d) issue_meta((gn >> 2) + 1, lo, d, mb);
                 }
-                issue_rows(std::integral_constant<int, SN>{}, gn, mb);
+                issue_rows(SN, gn, mb);
             }
             // the row's last group: the NEXT row's first metadata block is requested now (its buffer, the one behind this
             // row's last block, is free) and has a group of MFMAs to arrive before prime() waits for it
@@ -296,8 +298,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             }(std::make_integer_sequence<int, 4>{});
         };
         // ---- A (X6): one chunk = groups G, G + 1 = ring slots S, S + 1 (S = 0 or 2)
-        auto chunk = [&](auto slot, int G) {
-            constexpr int S = decltype(slot)::value;
+        auto chunk = [&](int S, int G) {                         // S = G & 2: ring slots S, S + 1
             if (G >= ngroups) return;
             const bool lastc = G + 2 >= ngroups;                 // the row's last chunk
             if (lastc && itn < count) issue_meta(0, lon, dn, mbn);
@@ -308,24 +309,25 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             else if (itn < count) dl_wait_vm<2>();
             else dl_wait_vm<0>();
             // all LDS operands of the chunk into registers: 8 entries x 2 pieces, their weights and border values
-            const unsigned par = ((mb + (G >> 2)) & 3) * 256;
+            const unsigned par = ((mb + (G >> 2)) & 3) * 256 + S * 64;
+            const unsigned ring_s = ring6_rd + S * DL_SLOT;
             f32x4 xr[8][2], wq[2], bq[2], bbq[2];
             auto read_entry = [&](auto jc) {
                 constexpr int jj = decltype(jc)::value;
-                xr[jj][0] = dl_read128<S * DL_SLOT + jj * RB>(ring6_rd);
-                if constexpr (J == 2) xr[jj][1] = dl_read128<S * DL_SLOT + jj * RB + 256>(ring6_rd);
+                xr[jj][0] = dl_read128<jj * RB>(ring_s);
+                if constexpr (J == 2) xr[jj][1] = dl_read128<jj * RB + 256>(ring_s);
                 else xr[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             };
             [&]<int... Js>(std::integer_sequence<int, Js...>) {
                 (read_entry(std::integral_constant<int, Js>{}), ...);
             }(std::make_integer_sequence<int, 8>{});
-            wq[0] = dl_read128<DL_W + S * 64>(meta6_rd + par);
-            wq[1] = dl_read128<DL_W + S * 64 + 16>(meta6_rd + par);
+            wq[0] = dl_read128<DL_W>(meta6_rd + par);
+            wq[1] = dl_read128<DL_W + 16>(meta6_rd + par);
             if constexpr (BORDER) {
-                bq[0] = dl_read128<DL_BD + S * 64>(meta6_rd + par);
-                bq[1] = dl_read128<DL_BD + S * 64 + 16>(meta6_rd + par);
-                bbq[0] = dl_read128<DL_BB + S * 64>(meta6_rd + par);
-                bbq[1] = dl_read128<DL_BB + S * 64 + 16>(meta6_rd + par);
+                bq[0] = dl_read128<DL_BD>(meta6_rd + par);
+                bq[1] = dl_read128<DL_BD + 16>(meta6_rd + par);
+                bbq[0] = dl_read128<DL_BB>(meta6_rd + par);
+                bbq[1] = dl_read128<DL_BB + 16>(meta6_rd + par);
             } else {
                 bq[0] = bq[1] = bbq[0] = bbq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -335,13 +337,13 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
                            "+v"(xr[7][0]), "+v"(xr[7][1]), "+v"(wq[0]), "+v"(wq[1]), "+v"(bq[0]), "+v"(bq[1]), "+v"(bbq[0]), "+v"(bbq[1])::"memory");
             // the two slots are free again: request groups G + 4, G + 5 into them (the first of them opens a block when S == 0)
             if (G + 4 < ngroups) {
-                if constexpr (S == 0) {
+                if (S == 0) {
                     issue_border((G >> 2) + 1, mb);              // its indices are older than the groups just waited for
                 } else {
                     if (64 * ((G >> 2) + 2) < d) issue_meta((G >> 2) + 2, lo, d, mb);    // two blocks on: needed in the next trip
                 }
-                issue_rows(std::integral_constant<int, S>{}, G + 4, mb);
-                if (G + 5 < ngroups) issue_rows(std::integral_constant<int, S + 1>{}, G + 5, mb);
+                issue_rows(S, G + 4, mb);
+                if (G + 5 < ngroups) issue_rows(S + 1, G + 5, mb);
             }
             if (WMF_ABL(dbg, 2)) return;
             // right-hand side and border on the VALU from the raw values; MFMA operands scaled by sqrt(w) and split.
@@ -399,10 +401,12 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
                 }
             }
         };
-        for (int G0 = 0; G0 < ngroups; G0 += DL_R) {
+        if constexpr (X6) {
+#pragma unroll 1
+            for (int G = 0; G < ngroups; G += 2) chunk(G & 2, G);
+        }
+        for (int G0 = 0; G0 < (X6 ? 0 : ngroups); G0 += DL_R) {
             if constexpr (X6) {
-                chunk(std::integral_constant<int, 0>{}, G0);
-                chunk(std::integral_constant<int, 2>{}, G0 + 2);
             } else {
                 [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
                     (step(std::integral_constant<int, Ss>{}, G0 + Ss), ...);
