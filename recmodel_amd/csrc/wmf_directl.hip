@@ -376,16 +376,26 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
                         const float sx = x * swj[j];
                         const _Float16 h = (_Float16)sx;
                         hi[bj][j] = h;
-                        lo3[bj][j] = DL_LOMODE == 1 ? (_Float16)0.f : (DL_LOMODE == 2 ? (_Float16)((float)h - sx) : (_Float16)(sx - (float)h));
+#if DL_LOMODE == 0
+                        // the low part against the EXACT product (one v_fma_mix_f32: f32 x f32 - f16): hi + lo is then x sqrt(w)
+                        // to 2^-22 whatever the rounding of sx was
+                        lo3[bj][j] = (_Float16)__builtin_fmaf(x, swj[j], -(float)h);
+#else
+                        lo3[bj][j] = DL_LOMODE == 1 ? (_Float16)0.f : (_Float16)((float)h - sx);
+#endif
                     }
                 }
             };
-            // Block column by block column, the split of column bj + 1 in front of the MFMAs of column bj, which it does not
-            // depend on; hipcc hoists most of the split in front of a burst of MFMAs.  A hand-pipelined version (MFMAs of chunk
-            // c between the split units of chunk c + 1, order pinned by sched_barrier, ring reads two entry pairs ahead behind
-            // counted lgkmcnt waits: tools/lab/wmf_directl_pipe_attempt.hip.txt) computed the same rows and was SLOWER, 29.0
-            // against 26.9 ms at cfg3: with the split-f16 products this phase is 9.4 of the kernel's 25 ms (ablation, -DWMF_LAB
-            // flag 1) and waits for its LDS-DMA rows (SQ_WAIT_ANY 15 k of 57 k cycles per row), not for issue slots.
+            // (A hand-pipelined version -- MFMAs of chunk c between the split units of chunk c + 1, ring reads two entry pairs
+            // ahead behind counted lgkmcnt waits: tools/lab/wmf_directl_pipe_attempt.hip.txt -- computed the same rows and was
+            // slower, 29.0 against 26.9 ms at the time.)
+            // Block column by block column, the split of column bj + 1 in front of the MFMAs of column bj.  hipcc puts ~340 of the
+            // chunk's ~440 VALU instructions in front of the first MFMA and 80 of the 108 MFMAs behind the last one; pinning
+            // each tile's three MFMAs together with a slice of the next column's split (sched_barrier) interleaves them as
+            // intended and changes NOTHING (22.05 vs 22.11 ms at cfg3), and sched_group_barrier patterns make hipcc separate
+            // them completely: on this kernel VALU time, MFMA pipe time and waits simply add up (rocprofv3 --pmc, cfg3 item
+            // side: VALU active 63 % of the SIMD cycles, SQ_VALU_MFMA_BUSY_CYCLES 19 % = 16 cycles per f16 MFMA, SQ_WAIT_ANY
+            // 19 %), so what shortens the phase is fewer instructions, not their order.
             split(0);
 #pragma unroll
             for (int bj = 0; bj < NFB; ++bj) {
