@@ -41,6 +41,31 @@ __device__ __forceinline__ void wmf_row16_sum4(float& a, float& b, float& c, flo
 #undef WMF_STAGE
 }
 
+// Four row sums for the price of less than three: each exchange stage also HALVES the number of values a lane carries
+// (it keeps the half its partner sends it and sends the other one), so the stages cost 4 + 2, 2 + 1, 1, 1 instructions
+// instead of 4 each.  On return `a` holds, on every lane (r, .), the 16-lane sum of input number 2 (r >> 3) + ((r >> 2) & 1)
+// -- a for r = 0..3, b for 4..7, c for 8..11, d for 12..15; b, c, d are clobbered.
+__device__ __forceinline__ void wmf_row16_sum4_scatter(float& a, float& b, float& c, float& d) {
+    float t0, t1;
+    asm volatile("s_nop 1\n\t"
+                 "v_cndmask_b32 %4, %2, %0, %6\n\t"            // r >= 8 keeps (c, d) and sends (a, b); r < 8 the other way round
+                 "v_cndmask_b32 %5, %3, %1, %6\n\t"
+                 "v_cndmask_b32 %0, %0, %2, %6\n\t"
+                 "v_cndmask_b32 %1, %1, %3, %6\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %5, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cndmask_b32 %4, %1, %0, %7\n\t"            // r & 4 keeps the second of the two and sends the first
+                 "v_cndmask_b32 %0, %0, %1, %7\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1)
+                 : "s"(0xFF00FF00FF00FF00ull), "s"(0xF0F0F0F0F0F0F0F0ull));
+}
+
 // the same over the two 8-lane halves of each DPP row (lanes 16g .. 16g+7 and 16g+8 .. 16g+15) separately
 __device__ __forceinline__ void wmf_row8_sum4(float& a, float& b, float& c, float& d) {
 #define WMF_STAGE(ctrl)                                                  \

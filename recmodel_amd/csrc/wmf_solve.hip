@@ -378,11 +378,11 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
             y.x += p[1] * x[1][t].x; y.y += p[1] * x[1][t].y; y.z += p[1] * x[1][t].z; y.w += p[1] * x[1][t].w;
         }
 #if !(WMF_LOW_ABLATE & 4)
-        wmf_row16_sum4(y.x, y.y, y.z, y.w);
+        wmf_row16_sum4_scatter(y.x, y.y, y.z, y.w);     // y.x = the sum of component r >> 2, on the lanes r = 0, 4, 8, 12 among others
 #endif
         // the piece this lane holds in slot t (X6 with a last odd piece: lane q = 0 owns it)
         const int c = X6 ? ((TAIL && t == NCH - 1) ? (q == 0 ? nch - 1 : nch) : 8 * (t >> 1) + 2 * q + (t & 1)) : 4 * t + q;
-        if (r == 0 && c < nch) grow[c] = y;
+        if ((r & 3) == 0 && c < nch) reinterpret_cast<float*>(grow)[4 * c + (r >> 2)] = y.x;
     }
 }
 
