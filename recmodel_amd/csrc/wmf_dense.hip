@@ -940,7 +940,9 @@ __global__ __launch_bounds__(512) void transform6_kernel(const float* __restrict
             }
         }
     };
-    // one block of pieces at a time (two, as in transform_kernel, spill at 256 registers: the bf16 parts need room)
+    // one block of pieces at a time (two, as in transform_kernel, spill at 256 registers: the bf16 parts need room).  Two
+    // 16-row blocks per trip sharing every B operand read (twelve MFMAs per three ds_read_b128 instead of six) were measured in
+    // round 2: 256 registers + 244 bytes of scratch at NFB = 9, 3.9 ms per cfg3 half step against 2.4.
     float4 xa[2 * NKC];
     for (int64_t blk = (int64_t)blockIdx.x * 8 + wv; blk < nblocks16; blk += stride) {
         request(blk, xa);
