@@ -128,6 +128,54 @@ __device__ __forceinline__ float wmf_bcast_rowgroup(float v) {
     return __builtin_bit_cast(float, (KQ & 1) ? t[1] : t[0]);
 }
 
+// ---- split-f16 operands: x = hi + lo with hi = RN_f16(x) and lo = RN_f16(x - hi) (22 significand bits).  Written out as
+// instructions because hipcc takes the low part the long way round (v_cvt_f32_f16 of the high part, then a subtraction):
+// v_fma_mix_f32 reads the packed f16 high part directly, so four values cost 2 + 4 + 2 instructions instead of 12.
+// ONLY for values that come from loads or VALU arithmetic: hipcc does not look into an asm block, so it keeps neither the
+// wait states an MFMA result needs before a VALU instruction may read it, nor those an MFMA needs behind a VALU write of
+// its operand (the trailing s_nop below covers the second case; nothing cheap covers the first).  Bit-identical to the
+// C++ split (tools/lab/split_probe.hip).
+typedef unsigned wmf_u32x4 __attribute__((ext_vector_type(4)));
+// { hi(x0) hi(x1) | hi(x2) hi(x3) | lo(x0) lo(x1) | lo(x2) lo(x3) }
+__device__ __forceinline__ wmf_u32x4 wmf_split4(float x0, float x1, float x2, float x3) {
+    unsigned h01, h23, l01, l23;
+    float l0, l1, l2, l3;
+    asm("v_cvt_pk_f16_f32 %0, %6, %7\n\t"
+        "v_cvt_pk_f16_f32 %1, %8, %9\n\t"
+        "v_fma_mix_f32 %2, %6, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %3, %7, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %4, %8, 1.0, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %5, %9, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h01), "=&v"(h23), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+    // (the trailing s_nop: hipcc does not see what an asm block writes, so it cannot keep the two wait states an MFMA needs
+    // behind a VALU write of one of its operands -- a consumer one instruction further down read stale registers)
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5\n\ts_nop 1" : "=&v"(l01), "=v"(l23) : "v"(l0), "v"(l1), "v"(l2), "v"(l3));
+    return wmf_u32x4{h01, h23, l01, l23};
+}
+// the same for the scaled values x_i s_i: hi = RN_f16(RN_f32(x s)), lo against the EXACT product (fma), so hi + lo is x s to
+// 2^-22 whatever the rounding of the f32 product was
+__device__ __forceinline__ wmf_u32x4 wmf_split4_scaled(float x0, float x1, float x2, float x3, float s0, float s1, float s2, float s3) {
+    unsigned h01, h23, l01, l23;
+    float l0, l1, l2, l3;
+    asm("v_mul_f32 %2, %6, %10\n\t"
+        "v_mul_f32 %3, %7, %11\n\t"
+        "v_mul_f32 %4, %8, %12\n\t"
+        "v_mul_f32 %5, %9, %13\n\t"
+        "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_cvt_pk_f16_f32 %1, %4, %5\n\t"
+        "v_fma_mix_f32 %2, %6, %10, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %3, %7, %11, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %4, %8, %12, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %5, %9, %13, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h01), "=&v"(h23), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(s0), "v"(s1), "v"(s2), "v"(s3));
+    // (the trailing s_nop: hipcc does not see what an asm block writes, so it cannot keep the two wait states an MFMA needs
+    // behind a VALU write of one of its operands -- a consumer one instruction further down read stale registers)
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5\n\ts_nop 1" : "=&v"(l01), "=v"(l23) : "v"(l0), "v"(l1), "v"(l2), "v"(l3));
+    return wmf_u32x4{h01, h23, l01, l23};
+}
+
 // Sum of a value over the four 16-lane row groups, lane for lane, in every group: seven VALU instructions and no LDS round
 // trip (two ds_bpermute -- __shfl_xor 16, 32 -- cost a wave that runs alone on its SIMD some 200 exposed cycles).
 __device__ __forceinline__ float wmf_qsum(float v) {

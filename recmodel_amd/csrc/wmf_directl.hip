@@ -363,28 +363,29 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             }
             f16x8 hi[NFB], lo3[NFB];
             auto split = [&](int bj) {                           // right-hand side, border and the two f16 parts of block bj
+                float x[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float x = xr[j][bj >> 2][bj & 3];
-                    racc[bj] += x * pj[j];
-                    if constexpr (BORDER) bacc[bj] += x * bwj[j];
-                    {
-                        // No contraction in the split itself: with it hipcc forms the high part twice -- once from the f32
-                        // product (the operand the MFMAs get) and once more inside a v_fma_mix from the unrounded product
-                        // (the one the low part is taken against) -- and the two roundings can disagree by an f16 ulp.
-#pragma clang fp contract(off)
-                        const float sx = x * swj[j];
-                        const _Float16 h = (_Float16)sx;
-                        hi[bj][j] = h;
-#if DL_LOMODE == 0
-                        // the low part against the EXACT product (one v_fma_mix_f32: f32 x f32 - f16): hi + lo is then x sqrt(w)
-                        // to 2^-22 whatever the rounding of sx was
-                        lo3[bj][j] = (_Float16)__builtin_fmaf(x, swj[j], -(float)h);
-#else
-                        lo3[bj][j] = DL_LOMODE == 1 ? (_Float16)0.f : (_Float16)((float)h - sx);
-#endif
-                    }
+                    x[j] = xr[j][bj >> 2][bj & 3];
+                    racc[bj] += x[j] * pj[j];
+                    if constexpr (BORDER) bacc[bj] += x[j] * bwj[j];
                 }
+#if DL_LOMODE == 0
+                // hi = RN_f16(RN_f32(x sqrt(w))), lo against the exact product: wmf_split4_scaled (wmf_common.h)
+                const wmf_u32x4 s0 = wmf_split4_scaled(x[0], x[1], x[2], x[3], swj[0], swj[1], swj[2], swj[3]);
+                const wmf_u32x4 s1 = wmf_split4_scaled(x[4], x[5], x[6], x[7], swj[4], swj[5], swj[6], swj[7]);
+                hi[bj] = __builtin_bit_cast(f16x8, wmf_u32x4{s0[0], s0[1], s1[0], s1[1]});
+                lo3[bj] = __builtin_bit_cast(f16x8, wmf_u32x4{s0[2], s0[3], s1[2], s1[3]});
+#else
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+#pragma clang fp contract(off)
+                    const float sx = x[j] * swj[j];
+                    const _Float16 h = (_Float16)sx;
+                    hi[bj][j] = h;
+                    lo3[bj][j] = DL_LOMODE == 1 ? (_Float16)0.f : (_Float16)((float)h - sx);
+                }
+#endif
             };
             // (A hand-pipelined version -- MFMAs of chunk c between the split units of chunk c + 1, ring reads two entry pairs
             // ahead behind counted lgkmcnt waits: tools/lab/wmf_directl_pipe_attempt.hip.txt -- computed the same rows and was

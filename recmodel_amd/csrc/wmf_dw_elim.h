@@ -32,6 +32,8 @@ __device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for
 // with no cross-lane movement at all (slot (q, jj) means k = 4q + (jj & 3) on every lane).  Two 16-cycle MFMAs that leave
 // half their cycles to the VALU replace four 32-cycle ones; the splits cost 12 VALU instructions per tile of the pivot row.
 typedef _Float16 dw_f16x8 __attribute__((ext_vector_type(8)));
+// (Plain C++, not wmf_split4: these tiles are MFMA results, and hipcc keeps the wait states between an MFMA and a reader of its
+// result only for instructions it can see into -- an inline-asm reader scheduled right behind the MFMA reads stale registers.)
 __device__ __forceinline__ dw_f16x8 dw_split_natural(const f32x4 v) {
     dw_f16x8 o;
 #pragma unroll

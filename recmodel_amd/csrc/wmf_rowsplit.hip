@@ -28,7 +28,7 @@
 
 typedef _Float16 rs_f16x8 __attribute__((ext_vector_type(8)));
 // a tile's four values per lane (k = 4q + e) as { h_0..h_3, l_0..l_3 }: the "natural" split-f16 operand of wmf_dw_elim.h
-__device__ __forceinline__ rs_f16x8 rs_split_natural(const f32x4 v) {
+__device__ __forceinline__ rs_f16x8 rs_split_natural(const f32x4 v) {     // (C++ on purpose: see dw_split_natural, wmf_dw_elim.h)
     rs_f16x8 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {

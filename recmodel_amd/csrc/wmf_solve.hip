@@ -102,15 +102,11 @@ template <int E> __device__ __forceinline__ float low_elem(const float4& a, cons
 }
 // the two f16 parts of the eight values of pieces (a, b), scaled
 __device__ __forceinline__ void low_split8(const float4& a, const float4& b, low_f16x8& hi, low_f16x8& lo) {
-    const float xe[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-#pragma clang fp contract(off)                       // (with contraction hipcc forms the high part twice, differently rounded)
-        const float sx = xe[e] * WMF_LOW_SC;
-        const _Float16 h = (_Float16)sx;
-        hi[e] = h;
-        lo[e] = (_Float16)(sx - (float)h);
-    }
+    // (the scaling by a power of two is exact: split the scaled values)
+    const wmf_u32x4 s0 = wmf_split4(a.x * WMF_LOW_SC, a.y * WMF_LOW_SC, a.z * WMF_LOW_SC, a.w * WMF_LOW_SC);
+    const wmf_u32x4 s1 = wmf_split4(b.x * WMF_LOW_SC, b.y * WMF_LOW_SC, b.z * WMF_LOW_SC, b.w * WMF_LOW_SC);
+    hi = __builtin_bit_cast(low_f16x8, wmf_u32x4{s0[0], s0[1], s1[0], s1[1]});
+    lo = __builtin_bit_cast(low_f16x8, wmf_u32x4{s0[2], s0[3], s1[2], s1[3]});
 }
 template <int NCH, int NSETS, bool BLK, bool X6 = false>
 __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 4) ? 5 : 1)) void solve_low_kernel(const int32_t* __restrict__ rows, int64_t count,
