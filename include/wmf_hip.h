@@ -234,8 +234,9 @@ int wmf_profile_reset(void);
  * with running solves.  Every selection computes the same results (the parity suite runs under each of them):
  *       64 plain 32 x 32 Gauss-Jordan for rows with 17..32 entries, 256 no border column, 1024 run-time-indexed eight-wave
  *       kernel for f > 144, 2048 no two-rows-per-wave kernel, 4096 register-ring heavy kernel at k = 128 (instead of the
- *       LDS-DMA ring), 8192 f32 MFMA accumulation in the LDS-DMA kernel, 65536 LDS-DMA kernel also for f = 64 / 65,
- *       131072 f32 Gramian and 262144 f32 row transform for f = 97 .. 144, 524288 f32 S tiles for rows with 17..32 entries.
+ *       LDS-DMA ring), 8192 f32 MFMA accumulation in the LDS-DMA kernel, 65536 register-ring heavy kernel at k = 64 (instead of the LDS-DMA ring),
+ *       131072 f32 Gramian and 262144 f32 row transform for f = 97 .. 144, 524288 f32 S tiles for rows with <= 32 entries,
+ *       2097152 f32 MFMA kernel for f > 144 (it does not split rows above 4096 entries).
  * The ablation switches 1 / 2 / 8 (no elimination / no accumulation MFMAs / no tile inverse: results WRONG) exist only
  * in a -DWMF_LAB build; the shipped library returns WMF_EINVAL for them. */
 int wmf_debug_set_flags(int flags);

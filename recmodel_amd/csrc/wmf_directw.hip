@@ -299,9 +299,11 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
     const int32_t* rows = pl->rows[WMF_BIN_MFMA];
     const int64_t normal = pl->count[WMF_BIN_MFMA] - pl->heavy_count;
     // k = 128 with or without biases: the LDS-DMA ring kernel (wmf_directl.hip); debug flag 4096 keeps the register ring
-    // (f = 64 / 65 can run there too, debug flag 65536, but gains nothing: cfg2 item side 1.34 ms against 1.30 here)
+    // and k = 64 since round 2: with the split-f16 accumulation AND elimination the LDS-DMA kernel, two waves per SIMD there,
+    // takes 0.97 ms for cfg2's item side where the f32 register-ring kernel takes 1.39 (round 1, bf16 x 3 accumulation
+    // and f32 elimination: 1.34 against 1.30; debug flag 65536 keeps the register ring at k = 64)
     // (side: NULL, or the {last feature, bias} pairs of the split layout, V then being the packed body)
-    if (normal > 0 && wmf_directl_supported(f, ld) && !(dbg & 4096) && (f >= 128 || (dbg & 65536))) {
+    if (normal > 0 && wmf_directl_supported(f, ld) && !(dbg & 4096) && (f >= 128 || !(dbg & 65536))) {
         (void)wmf_launch_directl(rows, normal, V, side, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, st);
     } else if (normal > 0) {
         static const char* nm = wmf_kname("solve_directw_kernel<%d, 0, %s>", NFB, BORDER ? "true" : "false");
