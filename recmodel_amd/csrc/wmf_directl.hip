@@ -30,14 +30,17 @@
 #define DL_GJ_LDS 0                 // multiplier column of the tile inverse: 1 = ds_bpermute, 0 = two VALU lane swaps
 #endif
 #define DL_R 4                      // ring slots = groups per 64-entry block (the group loop is unrolled by it)
-#define DL_W 1024                   // metadata behind the ring: idx[4][64], w[4][64], border[4][64], bias[4][64], block b in buffer b & 3
-#define DL_BD 2048                  // (block b + 1 is requested while groups of b - 1 are still being consumed: three live blocks)
-#define DL_BB 3072                  // the fixed side's bias of the entries (split layout: the second float of their pairs)
+// metadata behind the ring: idx[4][BLK], w[4][BLK], border[4][BLK], bias[4][BLK] (BLK = 4 GE entries per block, block b in
+// buffer b & 3; block b + 1 is requested while groups of b - 1 are still being consumed: three live blocks) at byte offsets
+// 0, DL_W, DL_BD, DL_BB (the fixed side's bias: the second float of the pairs in the split layout) = multiples of DL_MARR(GE)
 // per width (NFB = 4: f = 64 / 65, NFB = 8: f = 128 / 129): bytes of the feature part of a row, of a 16-entry slot, of the ring
+// GE = entries per group (ring slot): 16, or 8 for the two-waves-per-SIMD variant at NFB = 8 (half the ring, metadata blocks
+// of 32 entries, 16-entry chunks with 16x16x16 MFMAs, w_p in LDS instead of registers -- 19 KB of LDS per wave)
 #define DL_RB(NFB) (64 * (NFB))
-#define DL_SLOTB(NFB) (16 * DL_RB(NFB))
-#define DL_METAB(NFB) (DL_R * DL_SLOTB(NFB))
-#define DL_LDSB(NFB) (DL_METAB(NFB) + 4 * 1024)
+#define DL_SLOTB(NFB, GE) ((GE) * DL_RB(NFB))
+#define DL_METAB(NFB, GE) (DL_R * DL_SLOTB(NFB, GE))
+#define DL_MARR(GE) (64 * (GE))     // bytes of one metadata array: four buffers of 4 GE entries
+#define DL_LDSB(NFB, GE) (DL_METAB(NFB, GE) + 4 * DL_MARR(GE) + ((GE) == 8 ? 1024 : 0))
 
 typedef const __attribute__((address_space(1))) void* dl_gptr;
 typedef __attribute__((address_space(3))) void* dl_lptr;
@@ -92,8 +95,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef DL_LOMODE
 #define DL_LOMODE 0          // lab: 1 = no low parts, 2 = low parts negated
 #endif
-template <int NFB, bool BORDER, bool X6>
-__global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(const int32_t* __restrict__ rows, int64_t count, const float* __restrict__ V,
+template <int NFB, bool BORDER, bool X6, int GE = 16>
+__global__ __launch_bounds__(64, (NFB <= 4 || GE == 8) ? 2 : 1) void solve_directl_kernel(const int32_t* __restrict__ rows, int64_t count, const float* __restrict__ V,
                                                               const float* __restrict__ side, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                               const float* __restrict__ vals, int f, int ld, float* __restrict__ g,
                                                               int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int dbg) {
@@ -102,13 +105,19 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
     const bool split = BORDER && side != nullptr;
     const int ldv = split ? f - 1 : ld;
     constexpr int NT = NFB * (NFB + 1) / 2;
-    constexpr int RB = DL_RB(NFB), DL_SLOT = DL_SLOTB(NFB), DL_META = DL_METAB(NFB);   // row bytes, slot bytes, metadata offset
+    static_assert(GE == 16 || (GE == 8 && X6), "8-entry groups: split-f16 path only");
+    constexpr int RB = DL_RB(NFB), DL_SLOT = DL_SLOTB(NFB, GE), DL_META = DL_METAB(NFB, GE);   // row bytes, slot bytes, metadata offset
+    constexpr int BLK = 4 * GE, MBUF = 4 * BLK; // entries per metadata block, bytes of one buffer of a metadata array
+    constexpr int DL_W = DL_MARR(GE), DL_BD = 2 * DL_MARR(GE), DL_BB = 3 * DL_MARR(GE);
+    constexpr int KC = 2 * GE;                  // X6: entries per chunk (two slots) = K of its MFMAs
+    constexpr int EL = KC / 4;                  // X6: entries per lane and chunk (lane (r, q): entries EL q .. EL q + EL - 1)
     constexpr int J = NFB / 4;                  // 16-byte pieces per lane and entry (pieces r, r + 16, ..)
     constexpr int PP = 4 * NFB;                 // pieces per row; one DMA instruction moves 64 / PP rows
-    constexpr int EPI = 64 / PP, NI = 16 / EPI; // entries per DMA instruction, DMA instructions per 16-entry group
+    constexpr int EPI = 64 / PP, NI = GE / EPI; // entries per DMA instruction, DMA instructions per group
+    static_assert(NI == 4 || NI == 8, "four or eight DMA instructions per group");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
-    const int r = lane & 15, q = lane >> 4, h = lane / PP;
+    const int r = lane & 15, q = lane >> 4;
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);   // LDS byte address of the region
     int baddr[4];
 #pragma unroll
@@ -116,10 +125,15 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
     // LDS byte addresses of this lane's reads (inline asm below)
     const unsigned ring_rd = lds0 + q * RB + r * 16;                                // + slot * DL_SLOT + t * 4 RB + piece * 256
     const unsigned meta_rd = lds0 + DL_META + q * 4;                               // + (block & 3) * 256 + (group in block * 16 + 2 t) * 4
-    const unsigned idx8_rd = lds0 + DL_META + h * 4;                              // + (block & 3) * 256 + group in block * 64
-    const unsigned ring6_rd = lds0 + q * 8 * RB + r * 16;                   // X6: entries 8 q + j of a chunk: + slot * DL_SLOT + j * RB + piece * 256
-    const unsigned meta6_rd = lds0 + DL_META + q * 32;                     // X6: their eight weights / border values
-    const int piece = (lane % PP) * 4;                                      // first float of this lane's piece
+    // Lane-derived addresses of the request side are recomputed where they are used (from a lane id the compiler cannot see
+    // through): kept live across the row loop they are what hipcc spills first, and a scratch reload is a VMEM operation --
+    // returned in order, so the s_waitcnt in front of its use drains every LDS-DMA of the ring.
+    // (v_mbcnt in a volatile asm, not threadIdx.x or the builtin: hipcc spills even v0, and a CSE'd builtin result as well)
+    auto fresh_lane = [&]() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
 
     // The ring starts as zeros.  A chunk of the X6 path reads 32 ring positions even where the row has fewer entries left;
     // those positions are cancelled by weight 0, which only works on finite data: after this, whatever is stale in the ring
@@ -127,7 +141,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
     {
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < DL_LDSB(NFB) / 1024; ++i)       // (the metadata buffers too: a stale index is then a valid row, 0)
+        for (int i = 0; i < DL_LDSB(NFB, GE) / 1024; ++i)   // (the metadata buffers too: a stale index is then a valid row, 0)
             asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + i * 1024 + lane * 16), "v"(z) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -138,19 +152,25 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
     // (metadata of block b of the row whose first block uses buffer `base`: buffer (base + b) & 3 -- the buffers rotate
     // across rows, so that the next row's first block can be requested while this row's last one is still in use)
     auto issue_meta = [&](int b, int64_t lo_, int d_, int base) {
-        const int64_t e = lo_ + min(64 * b + lane, d_ - 1);
-        const unsigned par = ((base + b) & 3) * 256;
-        __builtin_amdgcn_global_load_lds((dl_gptr)(indices + e), (dl_lptr)(smem + DL_META + par), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((dl_gptr)(vals + e), (dl_lptr)(smem + DL_META + DL_W + par), 4, 0, 0);
+        const int ln = fresh_lane();
+        const int64_t e = lo_ + min(BLK * b + ln, d_ - 1);
+        const unsigned par = ((base + b) & 3) * MBUF;
+        if (BLK == 64 || ln < BLK) {                           // (lane l writes dword l of the buffer: the buffer has BLK of them)
+            __builtin_amdgcn_global_load_lds((dl_gptr)(indices + e), (dl_lptr)(smem + DL_META + par), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((dl_gptr)(vals + e), (dl_lptr)(smem + DL_META + DL_W + par), 4, 0, 0);
+        }
     };
     // border feature of the entries of block b (its indices have landed)
     auto issue_border = [&](int b, int base) {
         if constexpr (BORDER) {
-            const unsigned par = ((base + b) & 3) * 256;
-            float iv = dl_read32<0>(lds0 + DL_META + par + lane * 4);
+            const unsigned par = ((base + b) & 3) * MBUF;
+            const int ln = fresh_lane();
+            float iv = dl_read32<0>(lds0 + DL_META + par + (ln & (BLK - 1)) * 4);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(iv)::"memory");     // the value passes through the wait: no use can move above it
             const int idx = __builtin_bit_cast(int, iv);
-            if (split) {
+            if (BLK < 64 && ln >= BLK) {
+                // (nothing to fetch for this lane: the buffer holds BLK entries)
+            } else if (split) {
                 // the pair {last feature, bias}: two dwords of one 8-byte word (the pairs of a million rows are 8 MB: L2 hits)
                 __builtin_amdgcn_global_load_lds((dl_gptr)(side + 2 * (int64_t)idx), (dl_lptr)(smem + DL_META + DL_BD + par), 4, 0, 0);
                 __builtin_amdgcn_global_load_lds((dl_gptr)(side + 2 * (int64_t)idx + 1), (dl_lptr)(smem + DL_META + DL_BB + par), 4, 0, 0);
@@ -164,7 +184,10 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
     // ONE loop body -- with the slot as a template constant the two unrolled bodies got different register assignments for
     // the accumulators and hipcc moved ~170 of them between AGPRs and VGPRs on every trip)
     auto issue_rows = [&](int S, int gi, int base) {
-        const unsigned par = ((base + (gi >> 2)) & 3) * 256 + S * 64;
+        const unsigned par = ((base + (gi >> 2)) & 3) * MBUF + S * (GE * 4);
+        const int ln = fresh_lane();
+        const unsigned idx8_rd = lds0 + DL_META + (ln / PP) * 4;     // + (block & 3) * MBUF + group in block * 4 GE
+        const int piece = (ln % PP) * 4;                             // first float of this lane's piece
         // this lane's rows: entries EPI i + h of the group, i = 0 .. NI - 1
         f32x2 i0 = dl_read2<0, EPI>(idx8_rd + par), i1 = dl_read2<2 * EPI, 3 * EPI>(idx8_rd + par);
         f32x2 i2 = f32x2{0.f, 0.f}, i3 = f32x2{0.f, 0.f};       // (not copies of i0: it is still in flight)
@@ -187,11 +210,11 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
     // first requests of a row: metadata of block 0 (and 1), border of block 0, groups 0 .. 2.  Nothing else of this wave
     // is in flight when this runs, so the vmcnt(0) in it waits for the row's own first metadata only.
     auto prime = [&](int64_t lo_, int d_, int base, bool meta0_requested) {
-        const int ng = (d_ + 15) >> 4;
+        const int ng = (d_ + GE - 1) / GE;
         if (!meta0_requested) issue_meta(0, lo_, d_, base);
         dl_wait_vm<0>();
         issue_border(0, base);
-        if (d_ > 64) issue_meta(1, lo_, d_, base);
+        if (d_ > BLK) issue_meta(1, lo_, d_, base);
         issue_rows(0, 0, base);
         if (ng > 1) issue_rows(1, 1, base);
         if (ng > 2) issue_rows(2, 2, base);
@@ -201,7 +224,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
     if (it < count) { item(it, u, lo, d); prime(lo, d, mb, false); }
 
     for (; it < count; it += gridDim.x) {
-        const int ngroups = (d + 15) >> 4;
+        const int ngroups = (d + GE - 1) / GE;
         const int64_t itn = it + gridDim.x;
         int un = 0, dn = 0;
         int64_t lon = 0;
@@ -230,7 +253,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
                     // metadata of block gn / 4 was requested 32 operations ago (its own group requests and three more)
                     dl_wait_vm<4 * NI>();
                     issue_border(gn >> 2, mb);
-                    if (64 * ((gn >> 2) + 1) < d) issue_meta((gn >> 2) + 1, lo, d, mb);
+                    if (BLK * ((gn >> 2) + 1) < d) issue_meta((gn >> 2) + 1, lo, d, mb);
                 }
                 issue_rows(SN, gn, mb);
             }
@@ -309,9 +332,11 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             else if (itn < count) dl_wait_vm<2>();
             else dl_wait_vm<0>();
             // all LDS operands of the chunk into registers: 8 entries x 2 pieces, their weights and border values
-            const unsigned par = ((mb + (G >> 2)) & 3) * 256 + S * 64;
-            const unsigned ring_s = ring6_rd + S * DL_SLOT;
-            f32x4 xr[8][2], wq[2], bq[2], bbq[2];
+            const unsigned par = ((mb + (G >> 2)) & 3) * MBUF + S * (GE * 4);
+            const int lnc = fresh_lane();
+            const unsigned ring_s = lds0 + (lnc >> 4) * EL * RB + (lnc & 15) * 16 + S * DL_SLOT;   // entries EL q + j of the chunk: + j * RB + piece * 256
+            const unsigned meta6_rd = lds0 + DL_META + (lnc >> 4) * EL * 4;                       // their EL weights / border values
+            f32x4 xr[EL][2], wq[2], bq[2], bbq[2];
             auto read_entry = [&](auto jc) {
                 constexpr int jj = decltype(jc)::value;
                 xr[jj][0] = dl_read128<jj * RB>(ring_s);
@@ -320,27 +345,34 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             };
             [&]<int... Js>(std::integer_sequence<int, Js...>) {
                 (read_entry(std::integral_constant<int, Js>{}), ...);
-            }(std::make_integer_sequence<int, 8>{});
+            }(std::make_integer_sequence<int, EL>{});
             wq[0] = dl_read128<DL_W>(meta6_rd + par);
-            wq[1] = dl_read128<DL_W + 16>(meta6_rd + par);
+            wq[1] = bq[0] = bq[1] = bbq[0] = bbq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EL == 8) wq[1] = dl_read128<DL_W + 16>(meta6_rd + par);
             if constexpr (BORDER) {
                 bq[0] = dl_read128<DL_BD>(meta6_rd + par);
-                bq[1] = dl_read128<DL_BD + 16>(meta6_rd + par);
                 bbq[0] = dl_read128<DL_BB>(meta6_rd + par);
-                bbq[1] = dl_read128<DL_BB + 16>(meta6_rd + par);
-            } else {
-                bq[0] = bq[1] = bbq[0] = bbq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (EL == 8) {
+                    bq[1] = dl_read128<DL_BD + 16>(meta6_rd + par);
+                    bbq[1] = dl_read128<DL_BB + 16>(meta6_rd + par);
+                }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(xr[0][0]), "+v"(xr[0][1]), "+v"(xr[1][0]), "+v"(xr[1][1]), "+v"(xr[2][0]), "+v"(xr[2][1]), "+v"(xr[3][0]),
-                           "+v"(xr[3][1]), "+v"(xr[4][0]), "+v"(xr[4][1]), "+v"(xr[5][0]), "+v"(xr[5][1]), "+v"(xr[6][0]), "+v"(xr[6][1]),
-                           "+v"(xr[7][0]), "+v"(xr[7][1]), "+v"(wq[0]), "+v"(wq[1]), "+v"(bq[0]), "+v"(bq[1]), "+v"(bbq[0]), "+v"(bbq[1])::"memory");
+            if constexpr (EL == 8) {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(xr[0][0]), "+v"(xr[0][1]), "+v"(xr[1][0]), "+v"(xr[1][1]), "+v"(xr[2][0]), "+v"(xr[2][1]), "+v"(xr[3][0]),
+                               "+v"(xr[3][1]), "+v"(xr[EL - 4][0]), "+v"(xr[EL - 4][1]), "+v"(xr[EL - 3][0]), "+v"(xr[EL - 3][1]), "+v"(xr[EL - 2][0]), "+v"(xr[EL - 2][1]),
+                               "+v"(xr[EL - 1][0]), "+v"(xr[EL - 1][1]), "+v"(wq[0]), "+v"(wq[1]), "+v"(bq[0]), "+v"(bq[1]), "+v"(bbq[0]), "+v"(bbq[1])::"memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(xr[0][0]), "+v"(xr[0][1]), "+v"(xr[1][0]), "+v"(xr[1][1]), "+v"(xr[2][0]), "+v"(xr[2][1]), "+v"(xr[3][0]),
+                               "+v"(xr[3][1]), "+v"(wq[0]), "+v"(bq[0]), "+v"(bbq[0])::"memory");
+            }
             // the two slots are free again: request groups G + 4, G + 5 into them (the first of them opens a block when S == 0)
             if (G + 4 < ngroups) {
                 if (S == 0) {
                     issue_border((G >> 2) + 1, mb);              // its indices are older than the groups just waited for
                 } else {
-                    if (64 * ((G >> 2) + 2) < d) issue_meta((G >> 2) + 2, lo, d, mb);    // two blocks on: needed in the next trip
+                    if (BLK * ((G >> 2) + 2) < d) issue_meta((G >> 2) + 2, lo, d, mb);   // two blocks on: needed in the next trip
                 }
                 issue_rows(S, G + 4, mb);
                 if (G + 5 < ngroups) issue_rows(S + 1, G + 5, mb);
@@ -349,10 +381,10 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             // right-hand side and border on the VALU from the raw values; MFMA operands scaled by sqrt(w) and split.
             // Block column by block column: the split of column bj + 1 (VALU) has no dependence on the MFMAs of column bj,
             // and a bf16 MFMA leaves half of its cycles to the VALU.
-            float wj[8], pj[8], swj[8], bwj[8];
+            float wj[EL], pj[EL], swj[EL], bwj[EL];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool real = 16 * G + 8 * q + j < d;
+            for (int j = 0; j < EL; ++j) {
+                const bool real = GE * G + EL * (lnc >> 4) + j < d;
                 const float wraw = split ? wq[j >> 2][j & 3] - bbq[j >> 2][j & 3] : wq[j >> 2][j & 3];
                 wj[j] = real ? wraw : 0.f;
                 pj[j] = real ? wraw + 1.f : 0.f;
@@ -361,11 +393,13 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
                 bwj[j] = bfv * wj[j];
                 if constexpr (BORDER) { cacc += bfv * bwj[j]; eacc += bfv * pj[j]; }
             }
-            f16x8 hi[NFB], lo3[NFB];
+            // the two f16 parts of a block column: EL halves each (f16x8 for 32-entry chunks, f16x4 for 16-entry chunks)
+            typedef _Float16 f16xe __attribute__((ext_vector_type(EL)));
+            f16xe hi[NFB], lo3[NFB];
             auto split = [&](int bj) {                           // right-hand side, border and the two f16 parts of block bj
-                float x[8];
+                float x[EL];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < EL; ++j) {
                     x[j] = xr[j][bj >> 2][bj & 3];
                     racc[bj] += x[j] * pj[j];
                     if constexpr (BORDER) bacc[bj] += x[j] * bwj[j];
@@ -373,12 +407,18 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
 #if DL_LOMODE == 0
                 // hi = RN_f16(RN_f32(x sqrt(w))), lo against the exact product: wmf_split4_scaled (wmf_common.h)
                 const wmf_u32x4 s0 = wmf_split4_scaled(x[0], x[1], x[2], x[3], swj[0], swj[1], swj[2], swj[3]);
-                const wmf_u32x4 s1 = wmf_split4_scaled(x[4], x[5], x[6], x[7], swj[4], swj[5], swj[6], swj[7]);
-                hi[bj] = __builtin_bit_cast(f16x8, wmf_u32x4{s0[0], s0[1], s1[0], s1[1]});
-                lo3[bj] = __builtin_bit_cast(f16x8, wmf_u32x4{s0[2], s0[3], s1[2], s1[3]});
+                if constexpr (EL == 8) {
+                    const wmf_u32x4 s1 = wmf_split4_scaled(x[EL - 4], x[EL - 3], x[EL - 2], x[EL - 1], swj[EL - 4], swj[EL - 3], swj[EL - 2], swj[EL - 1]);
+                    hi[bj] = __builtin_bit_cast(f16xe, wmf_u32x4{s0[0], s0[1], s1[0], s1[1]});
+                    lo3[bj] = __builtin_bit_cast(f16xe, wmf_u32x4{s0[2], s0[3], s1[2], s1[3]});
+                } else {
+                    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+                    hi[bj] = __builtin_bit_cast(f16xe, u32x2_{s0[0], s0[1]});
+                    lo3[bj] = __builtin_bit_cast(f16xe, u32x2_{s0[2], s0[3]});
+                }
 #else
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < EL; ++j) {
 #pragma clang fp contract(off)
                     const float sx = x[j] * swj[j];
                     const _Float16 h = (_Float16)sx;
@@ -397,6 +437,18 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
             // them completely: on this kernel VALU time, MFMA pipe time and waits simply add up (rocprofv3 --pmc, cfg3 item
             // side: VALU active 63 % of the SIMD cycles, SQ_VALU_MFMA_BUSY_CYCLES 19 % = 16 cycles per f16 MFMA, SQ_WAIT_ANY
             // 19 %), so what shortens the phase is fewer instructions, not their order.
+            auto mfma3 = [&](const f16xe& al, const f16xe& ah, const f16xe& bl, const f16xe& bh, f32x4 c) {
+                if constexpr (EL == 8) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+                } else {
+                    c = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c, 0, 0, 0);
+                }
+                return c;
+            };
             split(0);
 #pragma unroll
             for (int bj = 0; bj < NFB; ++bj) {
@@ -404,11 +456,7 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
 #pragma unroll
                 for (int bi = 0; bi <= bj; ++bi) {
                     const int tt = tile_w<NFB>(bi, bj);
-                    f32x4 c = acc[tt];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo3[bi], hi[bj], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi[bi], lo3[bj], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi[bi], hi[bj], c, 0, 0, 0);
-                    acc[tt] = c;
+                    acc[tt] = mfma3(lo3[bi], hi[bi], lo3[bj], hi[bj], acc[tt]);
                 }
             }
         };
@@ -440,7 +488,10 @@ __global__ __launch_bounds__(64, NFB <= 4 ? 2 : 1) void solve_directl_kernel(con
                 cacc *= S2; eacc *= S2;
             }
         }
-        dw_eliminate<NFB, BORDER, (DL_GJ_LDS != 0), true, (X6 && DL_F16T != 0)>(acc, racc, bacc, cacc, eacc, nullptr, nullptr, r, q, baddr, dbg, gb, tb, ok,
+        // (GE == 8: w_p / w^b_p of the pivots in LDS behind the metadata -- 64 registers the two-waves variant does not have)
+        float* Wv = reinterpret_cast<float*>(smem + DL_META + 4 * DL_MARR(GE));
+        dw_eliminate<NFB, BORDER, (DL_GJ_LDS != 0), (GE != 8), (X6 && DL_F16T != 0), (GE == 8)>(acc, racc, bacc, cacc, eacc, GE == 8 ? Wv : nullptr,
+                                                          GE == 8 ? Wv + 16 * NFB : nullptr, r, q, baddr, dbg, gb, tb, ok,
                                                           X6 ? DL_S * DL_S : 1.f);
         if (!ok) {
             if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = u;
@@ -474,10 +525,23 @@ int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const
     const int dbg = wmf_debug_flags;
     const bool x6 = !(dbg & 8192);                              // debug flag 8192: f32 MFMA accumulation
 #define DL_LAUNCH(N, B, X) WMF_LAUNCH("solve_directl_kernel<" #N ", " #B ", " #X ">", (solve_directl_kernel<N, B, X>), grid, dim3(64), \
-                                      DL_LDSB(N), st, rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg)
+                                      DL_LDSB(N, 16), st, rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg)
 #define DL_PICK(N) do { if (f % 16) { if (x6) DL_LAUNCH(N, true, true); else DL_LAUNCH(N, true, false); } \
                         else        { if (x6) DL_LAUNCH(N, false, true); else DL_LAUNCH(N, false, false); } } while (0)
-    if (nfb == 4) DL_PICK(4); else DL_PICK(8);
+    if (nfb == 4) DL_PICK(4);
+    else if (x6 && (dbg & 16777216)) {
+        // lab: 8-entry groups (16 KB ring, 16-entry chunks with 16x16x16 MFMAs, w_p in LDS, lane coordinates re-formed at
+        // every pivot), TWO waves per SIMD on 256 registers each.  The second wave does overlap -- rocprofv3 --pmc at cfg3:
+        // VALU active 74 % + MFMA busy 34 % of the SIMD cycles where the one-wave kernel shows 63 + 19 -- but hipcc needs
+        // ~300 registers for this code: every scratch reload is a VMEM operation that returns in order, i.e. behind every
+        // LDS-DMA of the ring (27.3 ms with reloads inside the chunk loop, 21.0 with none there and 36 registers of row-0
+        // tiles spilled across the elimination, against 21.2 for the default kernel).  Not the default: 1 %.
+        const dim3 grid2((unsigned)(count < 2 * cap ? count : 2 * cap));
+        if (f % 16) WMF_LAUNCH("solve_directl_kernel<8, true, true, 8>", (solve_directl_kernel<8, true, true, 8>), grid2, dim3(64), DL_LDSB(8, 8), st,
+                               rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg);
+        else WMF_LAUNCH("solve_directl_kernel<8, false, true, 8>", (solve_directl_kernel<8, false, true, 8>), grid2, dim3(64), DL_LDSB(8, 8), st,
+                        rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg);
+    } else DL_PICK(8);
 #undef DL_PICK
 #undef DL_LAUNCH
     return 0;

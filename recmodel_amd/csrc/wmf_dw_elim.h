@@ -48,11 +48,23 @@ __device__ __forceinline__ dw_f16x8 dw_split_natural(const f32x4 v) {
 __device__ __forceinline__ dw_f16x8 dw_dup_hi(const dw_f16x8 n) { return __builtin_shufflevector(n, n, 0, 1, 2, 3, 0, 1, 2, 3); }
 __device__ __forceinline__ dw_f16x8 dw_dup_lo(const dw_f16x8 n) { return __builtin_shufflevector(n, n, 4, 5, 6, 7, 4, 5, 6, 7); }
 
-template <int NFB, bool BORDER, bool GJ_LDS, bool WREG = false, bool F16T = false>
+// RELANE: the lane coordinates (r, q) are formed again at every pivot from v_mbcnt in a volatile asm -- for the caller that
+// runs two waves per SIMD on 256 registers: kept live through the elimination they are spilled, and every scratch reload is
+// a VMEM operation that returns in order, behind all LDS-DMAs of the caller's ring.
+template <int NFB, bool BORDER, bool GJ_LDS, bool WREG = false, bool F16T = false, bool RELANE = false>
 __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], float (&racc)[NFB], float (&bacc)[BORDER ? NFB : 1],
-                                             float& cacc, float& eacc, float* Wv, float* Wb, int r,
-                                             int q, const int (&baddr)[4], int dbg, float (&gb)[NFB], float& tb, bool& ok,
+                                             float& cacc, float& eacc, float* Wv, float* Wb, int r_in,
+                                             int q_in, const int (&baddr)[4], int dbg, float (&gb)[NFB], float& tb, bool& ok,
                                              const float diag = 1.f) {
+    int r = r_in, q = q_in;
+    auto relane = [&]() {
+        if constexpr (RELANE) {
+            int l;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+            r = l & 15; q = l >> 4;
+        }
+    };
+    relane();
     float wvs[WREG ? NFB : 1][4], wbs[(WREG && BORDER) ? NFB : 1][4];
     int pmin = 0x7f800000;                                       // wave-uniform: smallest pivot of the tile inverses (bit pattern)
     float cacc2 = 0.f, eacc2 = 0.f;                              // BORDER: per-lane parts of the two border sums
@@ -92,10 +104,11 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
             if (diag != 1.f) X *= 1.f / diag;
             return X;
         };
-        f32x4 Xnext = invert(0);
+        f32x4 Xnext = RELANE ? f32x4{0.f, 0.f, 0.f, 0.f} : invert(0);       // (RELANE: no look-ahead, two waves hide the sweep's chain)
 #pragma unroll
         for (int p = 0; p < NFB; ++p) {
-            const f32x4 X = Xnext;
+            relane();
+            const f32x4 X = RELANE ? invert(p) : Xnext;
             // y_p[r] complete (its four q shares added), then w_p = X y_p: lane (r, q) has X[4q + reg][r] (X is
             // symmetric), so the products summed over the 16 lanes of a DPP row give w_p[4q + reg] on the whole row
             float yp = racc[p];
@@ -157,7 +170,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
                         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, nw[j], c, 0, 0, 0);
                         acc[t] = c;
                     }
-                    if (i == p + 1) Xnext = invert(p + 1);           // tile (p + 1, p + 1) is final: look ahead
+                    if (!RELANE && i == p + 1) Xnext = invert(p + 1); // tile (p + 1, p + 1) is final: look ahead
                 }
             } else {
                 // Row p: W_pj = X B_pj replaces the tile, the original goes to `orig` for the trailing update.  Both operands
@@ -188,7 +201,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
     #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[t] = WMF_MFMA16(a[e], acc[tw][e], acc[t]);
                     }
-                    if (i == p + 1) Xnext = invert(p + 1);           // tile (p + 1, p + 1) is final: look ahead
+                    if (!RELANE && i == p + 1) Xnext = invert(p + 1); // tile (p + 1, p + 1) is final: look ahead
                 }
             }
         }
@@ -213,6 +226,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
     if (!WMF_ABL(dbg, 1)) {
 #pragma unroll
         for (int p = NFB - 1; p >= 0; --p) {
+            relane();
             float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = p + 1; j < NFB; ++j) {

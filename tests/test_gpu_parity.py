@@ -327,6 +327,13 @@ def test_many_heavy_rows_per_wave_at_k128(WMF, bias):
     want = (orc.recompute_factors_bias if bias else orc.recompute_factors)(Y, C.astype(np.float64), 0.1, out_dtype="float64")
     rel_o, zero_abs = worst_row(got, want)
     assert fro(got, want) <= HALF_FRO and rel_o <= HALF_ROW and zero_abs == 0.0, (fro(got, want), rel_o)
+    try:                                                               # the two-waves-per-SIMD variant (8-entry groups, lab flag)
+        lib.wmf_debug_set_flags(16777216)
+        got8 = step(Y, C, 0.1).astype(np.float64)
+    finally:
+        lib.wmf_debug_set_flags(0)
+    rel_8, zero_8 = worst_row(got8, want)
+    assert fro(got8, want) <= HALF_FRO and rel_8 <= HALF_ROW and zero_8 == 0.0, (fro(got8, want), rel_8)
     # the two kernels differ in arithmetic (split-f16 products with an LDS-DMA ring here, f32 MFMAs from a register ring
     # there): they agree to the accuracy either has against the oracle, far inside the row tolerance
     rel = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
