@@ -529,13 +529,14 @@ int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const
 #define DL_PICK(N) do { if (f % 16) { if (x6) DL_LAUNCH(N, true, true); else DL_LAUNCH(N, true, false); } \
                         else        { if (x6) DL_LAUNCH(N, false, true); else DL_LAUNCH(N, false, false); } } while (0)
     if (nfb == 4) DL_PICK(4);
-    else if (x6 && (dbg & 16777216)) {
-        // lab: 8-entry groups (16 KB ring, 16-entry chunks with 16x16x16 MFMAs, w_p in LDS, lane coordinates re-formed at
-        // every pivot), TWO waves per SIMD on 256 registers each.  The second wave does overlap -- rocprofv3 --pmc at cfg3:
-        // VALU active 74 % + MFMA busy 34 % of the SIMD cycles where the one-wave kernel shows 63 + 19 -- but hipcc needs
-        // ~300 registers for this code: every scratch reload is a VMEM operation that returns in order, i.e. behind every
-        // LDS-DMA of the ring (27.3 ms with reloads inside the chunk loop, 21.0 with none there and 36 registers of row-0
-        // tiles spilled across the elimination, against 21.2 for the default kernel).  Not the default: 1 %.
+    else if (x6 && !(dbg & 16777216)) {
+        // k = 128: 8-entry groups (16 KB ring, 16-entry chunks with 16x16x16 MFMAs, w_p in LDS by inline asm, lane coordinates
+        // re-formed at every pivot), TWO waves per SIMD on 256 registers each (249 used, no scratch).  The second wave
+        // overlaps what one wave cannot -- rocprofv3 --pmc at cfg3: VALU active 80 % + MFMA busy 38 % of the SIMD cycles,
+        // SQ_WAIT_ANY 16 % of the wave cycles, where the one-wave kernel (debug flag 16777216) shows 63 + 19 and 19 that
+        // add up -- for 19.9 against 21.2 ms.  On the way there: every scratch reload is a VMEM operation that returns in
+        // order, i.e. behind every LDS-DMA of the ring (27.3 ms with reloads of spilled lane constants inside the chunk loop,
+        // 21.0 with none there, 19.9 with none at all); hipcc puts s_waitcnt vmcnt(0) in front of every LDS access it can see.
         const dim3 grid2((unsigned)(count < 2 * cap ? count : 2 * cap));
         if (f % 16) WMF_LAUNCH("solve_directl_kernel<8, true, true, 8>", (solve_directl_kernel<8, true, true, 8>), grid2, dim3(64), DL_LDSB(8, 8), st,
                                rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg);

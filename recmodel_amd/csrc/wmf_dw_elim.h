@@ -66,6 +66,20 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
     };
     relane();
     float wvs[WREG ? NFB : 1][4], wbs[(WREG && BORDER) ? NFB : 1][4];
+    // RELANE callers keep LDS-DMAs in flight across the elimination: their w_p vectors go to LDS by inline asm (hipcc puts an
+    // s_waitcnt vmcnt(0) in front of every LDS access it can see while an LDS-DMA may be outstanding)
+    constexpr bool WASM = RELANE && !WREG;
+    const unsigned wv_lds = WASM ? (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)Wv) : 0u;
+    const unsigned wb_lds = (WASM && BORDER) ? (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)Wb) : 0u;
+    auto lds_put4 = [&](unsigned base, int p, float a, float b, float c, float d) {     // every lane of group q: the same 16 bytes
+        const f32x4 v = f32x4{a, b, c, d};
+        asm volatile("ds_write_b128 %0, %1" ::"v"(base + (16 * p + 4 * q) * 4), "v"(v) : "memory");
+    };
+    auto lds_get4 = [&](unsigned base, int p) {
+        f32x4 v;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(base + (16 * p + 4 * q) * 4) : "memory");
+        return v;
+    };
     int pmin = 0x7f800000;                                       // wave-uniform: smallest pivot of the tile inverses (bit pattern)
     float cacc2 = 0.f, eacc2 = 0.f;                              // BORDER: per-lane parts of the two border sums
     // ---- C: block elimination, everything in registers except the two panel buffers
@@ -116,6 +130,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
             float wv0 = X[0] * yp, wv1 = X[1] * yp, wv2 = X[2] * yp, wv3 = X[3] * yp;
             wmf_row16_sum4(wv0, wv1, wv2, wv3);
             if constexpr (WREG) { wvs[p][0] = wv0; wvs[p][1] = wv1; wvs[p][2] = wv2; wvs[p][3] = wv3; }
+            else if constexpr (WASM) lds_put4(wv_lds, p, wv0, wv1, wv2, wv3);
             else if (r == 0) *reinterpret_cast<float4*>(&Wv[16 * p + 4 * q]) = make_float4(wv0, wv1, wv2, wv3);
             float wb0 = 0.f, wb1 = 0.f, wb2 = 0.f, wb3 = 0.f;
             if constexpr (BORDER) {
@@ -124,6 +139,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
                 wb0 = X[0] * bp; wb1 = X[1] * bp; wb2 = X[2] * bp; wb3 = X[3] * bp;
                 wmf_row16_sum4(wb0, wb1, wb2, wb3);
                 if constexpr (WREG) { wbs[p][0] = wb0; wbs[p][1] = wb1; wbs[p][2] = wb2; wbs[p][3] = wb3; }
+                else if constexpr (WASM) lds_put4(wb_lds, p, wb0, wb1, wb2, wb3);
                 else if (r == 0) *reinterpret_cast<float4*>(&Wb[16 * p + 4 * q]) = make_float4(wb0, wb1, wb2, wb3);
                 // b_p^T w^b_p and b_p^T w^y_p without moving anything: b_p[row] sits in lane r = row of every group and
                 // w_p[4q + reg] on every lane of group q, so the lanes with r >> 2 == q hold one product each (reg = r & 3);
@@ -209,7 +225,9 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
     // The backward pass reads what OTHER lanes (r == 0) stored into Wv / Wb above.  Per thread nothing orders a lane's load
     // after another lane's store, and hipcc did move the last pivot's load above the store for the lanes that do not
     // write; the wave-scope fence pair and the scheduling barrier pin the order the wave's lockstep execution relies on.
-    if constexpr (!WREG) {
+    if constexpr (WASM) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if constexpr (!WREG) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -236,10 +254,13 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
             }
             if (p + 1 < NFB) wmf_row16_sum4(s[0], s[1], s[2], s[3]);
             float gsel = 0.f;
+            f32x4 wl = f32x4{0.f, 0.f, 0.f, 0.f}, wbl = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (WASM) { wl = lds_get4(wv_lds, p); if constexpr (BORDER) wbl = lds_get4(wb_lds, p); }
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 float w;                                                              // w_p[4q + reg]
                 if constexpr (WREG) { w = wvs[p][reg]; if constexpr (BORDER) w -= tb * wbs[p][reg]; }
+                else if constexpr (WASM) { w = wl[reg]; if constexpr (BORDER) w -= tb * wbl[reg]; }
                 else { w = Wv[16 * p + 4 * q + reg]; if constexpr (BORDER) w -= tb * Wb[16 * p + 4 * q + reg]; }
                 const float gv = w - s[reg];                                         // g_p[4q + reg] on every lane (., q)
                 gsel = ((r & 3) == reg) ? gv : gsel;

@@ -327,7 +327,7 @@ def test_many_heavy_rows_per_wave_at_k128(WMF, bias):
     want = (orc.recompute_factors_bias if bias else orc.recompute_factors)(Y, C.astype(np.float64), 0.1, out_dtype="float64")
     rel_o, zero_abs = worst_row(got, want)
     assert fro(got, want) <= HALF_FRO and rel_o <= HALF_ROW and zero_abs == 0.0, (fro(got, want), rel_o)
-    try:                                                               # the two-waves-per-SIMD variant (8-entry groups, lab flag)
+    try:                                                               # the one-wave-per-SIMD variant (16-entry groups)
         lib.wmf_debug_set_flags(16777216)
         got8 = step(Y, C, 0.1).astype(np.float64)
     finally:
