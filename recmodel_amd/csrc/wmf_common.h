@@ -153,6 +153,24 @@ __device__ __forceinline__ wmf_u32x4 wmf_split4(float x0, float x1, float x2, fl
     asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5\n\ts_nop 1" : "=&v"(l01), "=v"(l23) : "v"(l0), "v"(l1), "v"(l2), "v"(l3));
     return wmf_u32x4{h01, h23, l01, l23};
 }
+// The same for values that may be MFMA RESULTS: twelve wait states in front (an 8-pass MFMA's result may be read by a VALU
+// instruction 11 cycles after the MFMA issued; hipcc inserts them for instructions it can see into, not for an asm block).
+// Worth it where a second wave fills the wait: four VALU instructions fewer per split.
+__device__ __forceinline__ wmf_u32x4 wmf_split4_after_mfma(float x0, float x1, float x2, float x3) {
+    unsigned h01, h23, l01, l23;
+    float l0, l1, l2, l3;
+    asm volatile("s_nop 7\n\ts_nop 3\n\t"
+        "v_cvt_pk_f16_f32 %0, %6, %7\n\t"
+        "v_cvt_pk_f16_f32 %1, %8, %9\n\t"
+        "v_fma_mix_f32 %2, %6, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %3, %7, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %4, %8, 1.0, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %5, %9, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h01), "=&v"(h23), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5\n\ts_nop 1" : "=&v"(l01), "=v"(l23) : "v"(l0), "v"(l1), "v"(l2), "v"(l3));
+    return wmf_u32x4{h01, h23, l01, l23};
+}
 // the same for the scaled values x_i s_i: hi = RN_f16(RN_f32(x s)), lo against the EXACT product (fma), so hi + lo is x s to
 // 2^-22 whatever the rounding of the f32 product was
 __device__ __forceinline__ wmf_u32x4 wmf_split4_scaled(float x0, float x1, float x2, float x3, float s0, float s1, float s2, float s3) {

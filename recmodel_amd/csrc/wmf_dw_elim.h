@@ -45,6 +45,10 @@ __device__ __forceinline__ dw_f16x8 dw_split_natural(const f32x4 v) {
     }
     return o;
 }
+// for callers that run two waves per SIMD (RELANE): the asm split behind explicit wait states
+__device__ __forceinline__ dw_f16x8 dw_split_natural_w(const f32x4 v) {
+    return __builtin_bit_cast(dw_f16x8, wmf_split4_after_mfma(v[0], v[1], v[2], v[3]));
+}
 __device__ __forceinline__ dw_f16x8 dw_dup_hi(const dw_f16x8 n) { return __builtin_shufflevector(n, n, 0, 1, 2, 3, 0, 1, 2, 3); }
 __device__ __forceinline__ dw_f16x8 dw_dup_lo(const dw_f16x8 n) { return __builtin_shufflevector(n, n, 4, 5, 6, 7, 4, 5, 6, 7); }
 
@@ -160,7 +164,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
                 f32x4 nX;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) nX[e] = -X[e];
-                const dw_f16x8 xn = dw_split_natural(nX), xh = dw_dup_hi(xn), xl = dw_dup_lo(xn);
+                const dw_f16x8 xn = (RELANE ? dw_split_natural_w(nX) : dw_split_natural(nX)), xh = dw_dup_hi(xn), xl = dw_dup_lo(xn);
                 dw_f16x8 nb[NFB], nw[NFB];
 #pragma unroll
                 for (int j = p + 1; j < NFB; ++j) {
@@ -168,12 +172,12 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
                     const f32x4 B = acc[t];
                     racc[j] -= B[0] * wv0 + B[1] * wv1 + B[2] * wv2 + B[3] * wv3;        // y_j[r] -= sum_rows B_pj[row][r] w_p[row]
                     if constexpr (BORDER) bacc[j] -= B[0] * wb0 + B[1] * wb1 + B[2] * wb2 + B[3] * wb3;
-                    nb[j] = dw_split_natural(B);
+                    nb[j] = RELANE ? dw_split_natural_w(B) : dw_split_natural(B);
                     f32x4 n = f32x4{0.f, 0.f, 0.f, 0.f};
                     n = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, nb[j], n, 0, 0, 0);
                     n = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, nb[j], n, 0, 0, 0);
                     acc[t] = n;                                  // W'_pj = -W_pj stays in registers for the backward pass too
-                    nw[j] = dw_split_natural(n);
+                    nw[j] = RELANE ? dw_split_natural_w(n) : dw_split_natural(n);
                 }
 #pragma unroll
                 for (int i = p + 1; i < NFB; ++i) {
