@@ -239,8 +239,11 @@ __device__ __forceinline__ void gj_inv_sweep(f32x4& a, const int (&baddr)[4], in
 // q == K / 4: one 16-lane group), and the multiplier is formed as  nf = (e_K - f) / piv,  e_K = [r == K]  -- which is
 // 1 / piv - 1 in the pivot row (f = piv there) and -f / piv elsewhere, the e_K doubling as the preset of column K.
 // 14 VALU instructions a step where the step above compiles to 19.  No pivot test: the caller checks the result.
-template <int K>
-__device__ __forceinline__ void gj_inv_step_lean(f32x4& a, int& pmin) {
+// BP: the multiplier column by ONE ds_bpermute_b32 (r4 = 4 (lane & 15), the row group in the instruction's offset field, the
+// wait in the same asm block so that hipcc sees neither) instead of five VALU instructions -- for callers that run two
+// waves per SIMD, where the permute's latency is the other wave's issue time.
+template <int K, bool BP = false>
+__device__ __forceinline__ void gj_inv_step_lean(f32x4& a, int& pmin, int r4 = 0) {
     constexpr int kq = K >> 2, kr = K & 3;
     const float akr = a[kr];
     const float piv = rlw(akr, K + 16 * kq);
@@ -249,7 +252,9 @@ __device__ __forceinline__ void gj_inv_step_lean(f32x4& a, int& pmin) {
     // (WMF_PIVOT_MIN_BITS) once.  A NaN passes, and reaches the solution, which the caller tests.
     pmin = min(pmin, __builtin_bit_cast(int, piv));
     const float inv = __builtin_amdgcn_rcpf(piv);
-    const float fk = wmf_bcast_rowgroup<kq>(akr);
+    float fk;
+    if constexpr (BP) asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)" : "=v"(fk) : "v"(r4), "v"(akr), "n"(64 * kq));
+    else fk = wmf_bcast_rowgroup<kq>(akr);
     // (the masks are shifted into place next to their use: as C++ constants hipcc computes all twenty once, ahead of the
     // eight sweeps of a row, and then spills them to VGPR lanes -- v_writelane / v_readlane around every use)
     float eK, pre;
@@ -266,9 +271,9 @@ __device__ __forceinline__ void gj_inv_step_lean(f32x4& a, int& pmin) {
     fmac_bcast4_self<K>(a0, a1, a2, a3, nf);
     a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3;
 }
-template <int... Ks>
-__device__ __forceinline__ void gj_inv_sweep_lean(f32x4& a, int& pmin, std::integer_sequence<int, Ks...>) {
-    (gj_inv_step_lean<Ks>(a, pmin), ...);
+template <bool BP = false, int... Ks>
+__device__ __forceinline__ void gj_inv_sweep_lean(f32x4& a, int& pmin, int r4, std::integer_sequence<int, Ks...>) {
+    (gj_inv_step_lean<Ks, BP>(a, pmin, r4), ...);
 }
 #define WMF_PIVOT_MIN_BITS 0x1e3ce508
 

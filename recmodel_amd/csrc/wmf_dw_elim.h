@@ -17,6 +17,11 @@ __device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for
     return bi * NFB - (bi * (bi - 1)) / 2 + (bj - bi);
 }
 
+#ifndef WMF_DW_BP
+#define WMF_DW_BP 0          // two-waves callers: multiplier column of the tile inverse by ds_bpermute instead of VALU lane swaps:
+                             // five VALU instructions fewer a step, measured 19.49 against 19.26 ms at cfg3 (the permute's latency
+                             // is not hidden when both waves of a SIMD sit in a sweep)
+#endif
 #ifndef WMF_DW_OPAQUE
 #define WMF_DW_OPAQUE 1
 #endif
@@ -104,7 +109,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
             // and vectors that still carry `diag`.
             if (diag != 1.f) X *= 1.f / diag;
             if constexpr (!GJ_LDS) {                                 // (the kernels whose wave runs alone on its SIMD)
-                if (!WMF_ABL(dbg, 8)) gj_inv_sweep_lean(X, pmin, std::make_integer_sequence<int, 16>{});
+                if (!WMF_ABL(dbg, 8)) gj_inv_sweep_lean<(RELANE && WMF_DW_BP != 0)>(X, pmin, 4 * r, std::make_integer_sequence<int, 16>{});
                 if (diag != 1.f) X *= 1.f / diag;
                 return X;
             }
