@@ -95,11 +95,17 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef DL_LOMODE
 #define DL_LOMODE 0          // lab: 1 = no low parts, 2 = low parts negated
 #endif
-template <int NFB, bool BORDER, bool X6, int GE = 16>
+// MODE 0: rows (accumulate + eliminate).  MODE 1: SEGMENTS of rows with more than WMF_HEAVY_T entries (wmf_plan): accumulate a
+// segment's entries and store its partial system in the layout of solve_directw_kernel's MODE 1, whose MODE 2 then adds a
+// row's segments and eliminates (wmf_directw.hip).
+template <int NFB, bool BORDER, bool X6, int GE = 16, int MODE = 0>
 __global__ __launch_bounds__(64, (NFB <= 4 || GE == 8) ? 2 : 1) void solve_directl_kernel(const int32_t* __restrict__ rows, int64_t count, const float* __restrict__ V,
                                                               const float* __restrict__ side, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                               const float* __restrict__ vals, int f, int ld, float* __restrict__ g,
-                                                              int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int dbg) {
+                                                              int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int dbg,
+                                                              const int64_t* __restrict__ seg_lo, const int32_t* __restrict__ seg_d,
+                                                              float* __restrict__ partial) {
+    static_assert(MODE == 0 || X6, "segments: split-f16 path only");
     // side != NULL (BORDER only): the split layout of a bias model's fixed side (wmf_internal.h) -- V holds packed body rows
     // of f - 1 = 16 NFB floats (exactly the RB bytes a ring row takes), side the {last feature, bias} pairs
     const bool split = BORDER && side != nullptr;
@@ -145,8 +151,9 @@ __global__ __launch_bounds__(64, (NFB <= 4 || GE == 8) ? 2 : 1) void solve_direc
             asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + i * 1024 + lane * 16), "v"(z) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    auto item = [&](int64_t i, int& u_, int64_t& lo_, int& d_) {
-        u_ = rows[i]; lo_ = indptr[u_]; d_ = (int)(indptr[u_ + 1] - lo_);
+    auto item = [&](int64_t i, int& u_, int64_t& lo_, int& d_) {     // work item i: a row, or (MODE 1) a segment
+        if constexpr (MODE == 1) { u_ = 0; lo_ = seg_lo[i]; d_ = seg_d[i]; }
+        else { u_ = rows[i]; lo_ = indptr[u_]; d_ = (int)(indptr[u_ + 1] - lo_); }
     };
     // metadata of block b of row (lo_, d_): lane l <- entry min(64 b + l, d_ - 1) (clamped entries get weight 0 at use)
     // (metadata of block b of the row whose first block uses buffer `base`: buffer (base + b) & 3 -- the buffers rotate
@@ -473,6 +480,34 @@ __global__ __launch_bounds__(64, (NFB <= 4 || GE == 8) ? 2 : 1) void solve_direc
             }
         }
         if (itn < count) prime(lon, dn, mbn, true);      // the next row's first entries fly during the elimination
+        if constexpr (MODE == 1) {                       // this segment's partial system (solve_directw_kernel MODE 1's layout)
+            const int ln = fresh_lane(), rr = ln & 15, qq = ln >> 4;
+            float* out = partial + it * (int64_t)WMF_DW_PARTIAL(NFB, BORDER);
+#pragma unroll
+            for (int bi = 0; bi < NFB; ++bi) {
+#pragma unroll
+                for (int bj = bi; bj < NFB; ++bj) {
+                    const int t = tile_w<NFB>(bi, bj);
+                    float* to = out + tile_off<NFB>(bi, bj);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        if (bi != bj) to[reg * 64 + ln] = acc[t][reg];
+                        else if (4 * qq + reg <= rr) to[rr * (rr + 1) / 2 + 4 * qq + reg] = acc[t][reg];   // element (4q + reg, r)
+                    }
+                }
+            }
+            float* vo = out + WMF_DW_TILES(NFB);
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) vo[fb * 64 + ln] = racc[fb];
+            if constexpr (BORDER) {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) vo[(NFB + fb) * 64 + ln] = bacc[fb];
+                vo[2 * NFB * 64 + ln] = cacc;
+                vo[(2 * NFB + 1) * 64 + ln] = eacc;
+            }
+            u = un; lo = lon; d = dn; mb = mbn;
+            continue;
+        }
 
         // ---- C, D: block elimination and backward pass (wmf_dw_elim.h), w_p in registers
         bool ok = true;
@@ -525,7 +560,8 @@ int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const
     const int dbg = wmf_debug_flags;
     const bool x6 = !(dbg & 8192);                              // debug flag 8192: f32 MFMA accumulation
 #define DL_LAUNCH(N, B, X) WMF_LAUNCH("solve_directl_kernel<" #N ", " #B ", " #X ">", (solve_directl_kernel<N, B, X>), grid, dim3(64), \
-                                      DL_LDSB(N, 16), st, rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg)
+                                      DL_LDSB(N, 16), st, rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, \
+                                      (const int64_t*)nullptr, (const int32_t*)nullptr, (float*)nullptr)
 #define DL_PICK(N) do { if (f % 16) { if (x6) DL_LAUNCH(N, true, true); else DL_LAUNCH(N, true, false); } \
                         else        { if (x6) DL_LAUNCH(N, false, true); else DL_LAUNCH(N, false, false); } } while (0)
     if (nfb == 4) DL_PICK(4);
@@ -539,11 +575,30 @@ int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const
         // 21.0 with none there, 19.9 with none at all); hipcc puts s_waitcnt vmcnt(0) in front of every LDS access it can see.
         const dim3 grid2((unsigned)(count < 2 * cap ? count : 2 * cap));
         if (f % 16) WMF_LAUNCH("solve_directl_kernel<8, true, true, 8>", (solve_directl_kernel<8, true, true, 8>), grid2, dim3(64), DL_LDSB(8, 8), st,
-                               rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg);
+                               rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, (const int64_t*)nullptr,
+                               (const int32_t*)nullptr, (float*)nullptr);
         else WMF_LAUNCH("solve_directl_kernel<8, false, true, 8>", (solve_directl_kernel<8, false, true, 8>), grid2, dim3(64), DL_LDSB(8, 8), st,
-                        rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg);
+                        rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, (const int64_t*)nullptr,
+                        (const int32_t*)nullptr, (float*)nullptr);
     } else DL_PICK(8);
 #undef DL_PICK
 #undef DL_LAUNCH
+    return 0;
+}
+
+// the segments of rows with more than WMF_HEAVY_T entries at k = 128 (+- biases): partial systems by the two-waves kernel
+int wmf_launch_directl_segments(int64_t nseg, const float* V, const float* side, const int32_t* indices, const float* vals, int f,
+                                int ld, const int64_t* seg_lo, const int32_t* seg_d, float* partial, hipStream_t st) {
+    if (nseg <= 0) return 0;
+    if (!((f == 128 && ld == 128) || (f == 129 && ld == 132))) return -1;
+    const int64_t cap = 256 * 4 * 2 * 3;
+    const dim3 grid((unsigned)(nseg < cap ? nseg : cap));
+    const int dbg = wmf_debug_flags;
+    if (f % 16) WMF_LAUNCH("solve_directl_kernel<8, true, true, 8, 1>", (solve_directl_kernel<8, true, true, 8, 1>), grid, dim3(64), DL_LDSB(8, 8), st,
+                           (const int32_t*)nullptr, nseg, V, side, (const int64_t*)nullptr, indices, vals, f, ld, (float*)nullptr,
+                           (int32_t*)nullptr, (int32_t*)nullptr, dbg, seg_lo, seg_d, partial);
+    else WMF_LAUNCH("solve_directl_kernel<8, false, true, 8, 1>", (solve_directl_kernel<8, false, true, 8, 1>), grid, dim3(64), DL_LDSB(8, 8), st,
+                    (const int32_t*)nullptr, nseg, V, side, (const int64_t*)nullptr, indices, vals, f, ld, (float*)nullptr,
+                    (int32_t*)nullptr, (int32_t*)nullptr, dbg, seg_lo, seg_d, partial);
     return 0;
 }

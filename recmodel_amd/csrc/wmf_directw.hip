@@ -76,14 +76,7 @@ struct DwCfg {
 // [reg][lane] (256 floats), a diagonal tile as its upper triangle only (136 floats, element (row <= col) at
 // col (col + 1) / 2 + row: partial systems cross xGMI in reduce mode, and the lower triangle is the same numbers) --
 // then y [fb][lane], then (BORDER) b [fb][lane], c [lane], e [lane]
-#define WMF_DW_TRI 136
-#define WMF_DW_TILES(NFB) (((NFB) * ((NFB) - 1) / 2) * 256 + (NFB) * WMF_DW_TRI)
-#define WMF_DW_PARTIAL(NFB, BORDER) (WMF_DW_TILES(NFB) + ((NFB) + ((BORDER) ? (NFB) + 2 : 0)) * 64)
-template <int NFB>
-__device__ __host__ constexpr int tile_off(int bi, int bj) {     // float offset of tile (bi, bj) in a partial system
-    const int t = bi * NFB - (bi * (bi - 1)) / 2 + (bj - bi), ndiag = bi + (bj > bi ? 1 : 0);
-    return (t - ndiag) * 256 + ndiag * WMF_DW_TRI;
-}
+// (WMF_DW_TRI, WMF_DW_TILES, WMF_DW_PARTIAL, tile_off: wmf_dw_elim.h -- the LDS-DMA kernel writes the same layout)
 
 template <int NFB, int MODE, bool BORDER>
 __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(const int32_t* __restrict__ rows, int64_t count,
@@ -315,6 +308,10 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
         const int64_t nseg = pl->seg_total;
         static const char* nm1 = wmf_kname("solve_directw_kernel<%d, 1, %s>", NFB, BORDER ? "true" : "false");
         static const char* nm2 = wmf_kname("solve_directw_kernel<%d, 2, %s>", NFB, BORDER ? "true" : "false");
+        // (k = 128: the segments through the LDS-DMA kernel as well -- same partial layout; debug flags 4096 / 16777216: here)
+        if (NFB == 8 && wmf_directl_supported(f, ld) && !(dbg & (4096 | 8192 | 16777216))) {
+            (void)wmf_launch_directl_segments(nseg, V, side, indices, vals, f, ld, pl->seg_lo, pl->seg_d, pl->partial, st);
+        } else
         WMF_LAUNCH(nm1, (solve_directw_kernel<NFB, 1, BORDER>), dim3((unsigned)(nseg < cap ? nseg : cap)), dim3(64), 0, st, rows,
                    nseg, V, side, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg, pl->seg_lo,
                    pl->seg_d, pl->seg_first, pl->partial, 1, 0);

@@ -17,6 +17,16 @@ __device__ __host__ constexpr int tile_w(int bi, int bj) {       // "for bi: for
     return bi * NFB - (bi * (bi - 1)) / 2 + (bj - bi);
 }
 
+// partial systems of split rows / of the reduce-scatter exchange (layout: header comment of wmf_directw.hip)
+#define WMF_DW_TRI 136
+#define WMF_DW_TILES(NFB) (((NFB) * ((NFB) - 1) / 2) * 256 + (NFB) * WMF_DW_TRI)
+#define WMF_DW_PARTIAL(NFB, BORDER) (WMF_DW_TILES(NFB) + ((NFB) + ((BORDER) ? (NFB) + 2 : 0)) * 64)
+template <int NFB>
+__device__ __host__ constexpr int tile_off(int bi, int bj) {     // float offset of tile (bi, bj) in a partial system
+    const int t = bi * NFB - (bi * (bi - 1)) / 2 + (bj - bi), ndiag = bi + (bj > bi ? 1 : 0);
+    return (t - ndiag) * 256 + ndiag * WMF_DW_TRI;
+}
+
 #ifndef WMF_DW_BP
 #define WMF_DW_BP 0          // two-waves callers: multiplier column of the tile inverse by ds_bpermute instead of VALU lane swaps:
                              // five VALU instructions fewer a step, measured 19.49 against 19.26 ms at cfg3 (the permute's latency

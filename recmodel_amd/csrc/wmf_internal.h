@@ -65,6 +65,8 @@ int wmf_directl_supported(int f, int ld);
 int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows, int32_t* fb_count,
                        hipStream_t st);
+int wmf_launch_directl_segments(int64_t nseg, const float* V, const float* side, const int32_t* indices, const float* vals, int f,
+                                int ld, const int64_t* seg_lo, const int32_t* seg_d, float* partial, hipStream_t st);
 int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* side, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int f, int ld, float* g, hipStream_t st);
 int64_t wmf_directw_partial_floats(int f);
