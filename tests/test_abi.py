@@ -61,6 +61,18 @@ def test_pure_host_entry_points(lib):
     assert lib.wmf_profile_entry(0, None, 0, None, None, None, None, None) == -1  # WMF_EINVAL, no entry 0
     assert lib.wmf_debug_set_flags(2) == -1                                      # ablation switches: -DWMF_LAB builds only
     assert lib.wmf_debug_set_flags(0) == 0
+    # the split layout of the whitened fixed side (k = 16 m with biases, m + 1 not a multiple of 4): the same predicate in
+    # the library and in the CPU stand-in the host-logic tests run on
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fake_kernels import NumpyKernels
+    fk = NumpyKernels()
+    for f in list(range(1, 150)) + [161, 193, 257]:
+        ld = lib.wmf_ld_for(f)
+        for bias in (0, 1):
+            assert lib.wmf_whitened_row_floats(f, ld, bias) == fk.whitened_row_floats(f, ld, bool(bias)), (f, bias)
+    assert [lib.wmf_whitened_row_floats(f, lib.wmf_ld_for(f), 1) for f in (17, 33, 49, 65, 113, 129, 145)] == [16, 32, 52, 64, 116, 128, 148]
+    assert lib.wmf_whitened_row_floats(129, 132, 0) == 132
 
 
 def test_argument_validation_without_gpu(lib):
