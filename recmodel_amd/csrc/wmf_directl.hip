@@ -92,6 +92,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef DL_F16T
 #define DL_F16T 1            // the elimination's tile products as split-f16 MFMAs too (wmf_dw_elim.h); 0: f32 MFMAs
 #endif
+#ifndef DL_PEEL
+#ifdef WMF_LAB
+#define DL_PEEL 0            // (the lab build's "no accumulation" switch needs initialised accumulators)
+#else
+#define DL_PEEL 1
+#endif
+#endif
 #ifndef DL_LOMODE
 #define DL_LOMODE 0          // lab: 1 = no low parts, 2 = low parts negated
 #endif
@@ -238,9 +245,15 @@ __global__ __launch_bounds__(64, (NFB <= 4 || GE == 8) ? 2 : 1) void solve_direc
         if (itn < count) item(itn, un, lon, dn);
         const int mbn = (mb + ((ngroups + 3) >> 2)) & 3;   // metadata buffer of the next row's block 0
 
+        // (DL_PEEL: the two-waves form takes the row's first chunk in a body of its own whose MFMAs start from C = 0 -- 144
+        // accumulator writes per row less; rows of the heavy bin have more than 32 entries, so that chunk always exists.
+        // MODE 1 segments may be shorter than a chunk, but never empty.)
+        constexpr bool PEEL = X6 && GE == 8 && DL_PEEL != 0;
         f32x4 acc[NT];
+        if constexpr (!PEEL) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         float racc[NFB], bacc[BORDER ? NFB : 1];
         float cacc = 0.f, eacc = 0.f;
 #pragma unroll
@@ -328,7 +341,8 @@ __global__ __launch_bounds__(64, (NFB <= 4 || GE == 8) ? 2 : 1) void solve_direc
             }(std::make_integer_sequence<int, 4>{});
         };
         // ---- A (X6): one chunk = groups G, G + 1 = ring slots S, S + 1 (S = 0 or 2)
-        auto chunk = [&](int S, int G) {                         // S = G & 2: ring slots S, S + 1
+        auto chunk = [&](int S, int G, auto first_c) {           // S = G & 2: ring slots S, S + 1
+            constexpr bool FIRST = decltype(first_c)::value;
             if (G >= ngroups) return;
             const bool lastc = G + 2 >= ngroups;                 // the row's last chunk
             if (lastc && itn < count) issue_meta(0, lon, dn, mbn);
@@ -463,13 +477,14 @@ __global__ __launch_bounds__(64, (NFB <= 4 || GE == 8) ? 2 : 1) void solve_direc
 #pragma unroll
                 for (int bi = 0; bi <= bj; ++bi) {
                     const int tt = tile_w<NFB>(bi, bj);
-                    acc[tt] = mfma3(lo3[bi], hi[bi], lo3[bj], hi[bj], acc[tt]);
+                    acc[tt] = mfma3(lo3[bi], hi[bi], lo3[bj], hi[bj], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[tt]);
                 }
             }
         };
+        if constexpr (PEEL) chunk(0, 0, std::true_type{});
         if constexpr (X6) {
 #pragma unroll 1
-            for (int G = 0; G < ngroups; G += 2) chunk(G & 2, G);
+            for (int G = PEEL ? 2 : 0; G < ngroups; G += 2) chunk(G & 2, G, std::false_type{});
         }
         for (int G0 = 0; G0 < (X6 ? 0 : ngroups); G0 += DL_R) {
             if constexpr (X6) {
