@@ -64,6 +64,21 @@ __device__ __forceinline__ dw_f16x8 dw_split_natural(const f32x4 v) {
 __device__ __forceinline__ dw_f16x8 dw_split_natural_w(const f32x4 v) {
     return __builtin_bit_cast(dw_f16x8, wmf_split4_after_mfma(v[0], v[1], v[2], v[3]));
 }
+// The same product from the two natural operands themselves, as three K = 16 MFMAs on their halves (hi.hi, hi.lo, lo.hi; lo.lo
+// is below 2^-22 of the product): no duplicated operands to build -- for the callers that are VALU bound with MFMA time to
+// spare (two waves per SIMD).
+typedef _Float16 dw_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 dw_prod16(const dw_f16x8 a, const dw_f16x8 b, f32x4 c) {
+    const dw_f16x4 ah = __builtin_shufflevector(a, a, 0, 1, 2, 3), al = __builtin_shufflevector(a, a, 4, 5, 6, 7);
+    const dw_f16x4 bh = __builtin_shufflevector(b, b, 0, 1, 2, 3), bl = __builtin_shufflevector(b, b, 4, 5, 6, 7);
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c, 0, 0, 0);
+    return c;
+}
+#ifndef WMF_DW_K16
+#define WMF_DW_K16 1
+#endif
 __device__ __forceinline__ dw_f16x8 dw_dup_hi(const dw_f16x8 n) { return __builtin_shufflevector(n, n, 0, 1, 2, 3, 0, 1, 2, 3); }
 __device__ __forceinline__ dw_f16x8 dw_dup_lo(const dw_f16x8 n) { return __builtin_shufflevector(n, n, 4, 5, 6, 7, 4, 5, 6, 7); }
 
@@ -189,8 +204,11 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
                     if constexpr (BORDER) bacc[j] -= B[0] * wb0 + B[1] * wb1 + B[2] * wb2 + B[3] * wb3;
                     nb[j] = RELANE ? dw_split_natural_w(B) : dw_split_natural(B);
                     f32x4 n = f32x4{0.f, 0.f, 0.f, 0.f};
-                    n = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, nb[j], n, 0, 0, 0);
-                    n = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, nb[j], n, 0, 0, 0);
+                    if constexpr (RELANE && WMF_DW_K16 != 0) n = dw_prod16(xn, nb[j], n);
+                    else {
+                        n = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, nb[j], n, 0, 0, 0);
+                        n = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, nb[j], n, 0, 0, 0);
+                    }
                     acc[t] = n;                                  // W'_pj = -W_pj stays in registers for the backward pass too
                     nw[j] = RELANE ? dw_split_natural_w(n) : dw_split_natural(n);
                 }
@@ -201,8 +219,11 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
                     for (int j = i; j < NFB; ++j) {
                         const int t = tile_w<NFB>(i, j);
                         f32x4 c = acc[t];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, nw[j], c, 0, 0, 0);     // B_ij += B_pi^T W'_pj
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, nw[j], c, 0, 0, 0);
+                        if constexpr (RELANE && WMF_DW_K16 != 0) c = dw_prod16(nb[i], nw[j], c);
+                        else {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, nw[j], c, 0, 0, 0);     // B_ij += B_pi^T W'_pj
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, nw[j], c, 0, 0, 0);
+                        }
                         acc[t] = c;
                     }
                     if (!RELANE && i == p + 1) Xnext = invert(p + 1); // tile (p + 1, p + 1) is final: look ahead
