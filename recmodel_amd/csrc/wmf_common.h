@@ -277,6 +277,39 @@ __device__ __forceinline__ void gj_inv_sweep_lean(f32x4& a, int& pmin, int r4, s
 }
 #define WMF_PIVOT_MIN_BITS 0x1e3ce508
 
+// The same inverse as a SYMMETRIC sweep whose rank-one update is one f32 MFMA -- for callers that run two waves per SIMD and
+// are bound by VALU issue, with MFMA time to spare.  The tile stays symmetric, so the row-distributed layout above is also
+// the accumulator layout of v_mfma_f32_16x16x4_f32 (lane (r, q), register e: element [4q + e][r]), and column K -- lane
+// (i, K / 4), register K & 3 -- is where the instruction reads A[i][k = K / 4] and B[k = K / 4][j] from.  Step K:
+//     u = column K with u[K] = piv - 1,   v = -u / piv  (so v[K] = 1 / piv - 1),   A += u v^T,   A[K][K] = -1 / piv
+// which is  A[i][j] -= A[i][K] A[K][j] / piv  off row and column K and scales those two by 1 / piv (the u[K], v[K] terms):
+// the sweep operator; after the sixteen steps the tile holds MINUS the inverse.  v is written into a register that is zero
+// outside lane group K / 4 (DPP row mask), which keeps the other three k slots of the instruction out of the sum.
+// 7 VALU instructions and one MFMA a step instead of 14.  Same pivot test and caveats as the lean step.
+template <int K>
+__device__ __forceinline__ void gj_sweep_step_mfma(f32x4& a, int& pmin, float (&vz)[4]) {
+    constexpr int kq = K >> 2, kr = K & 3;
+    const float akr = a[kr];
+    const float piv = rlw(akr, K + 16 * kq);
+    pmin = min(pmin, __builtin_bit_cast(int, piv));
+    const float inv = __builtin_amdgcn_rcpf(piv);
+    float eK;                                                    // 1 in lane (K, K / 4), 0 elsewhere
+    unsigned long long tmp;
+    asm volatile("s_lshl_b64 %1, 1, %2\n\tv_cndmask_b32 %0, 0, 1.0, %1" : "=v"(eK), "=&s"(tmp) : "n"(K + 16 * kq));
+    const float u = akr - eK;
+    // (two wait states between the VALU write of u and the DPP read, two between the write of v and the MFMA: hipcc keeps
+    // neither around an asm block)
+    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, -%2 quad_perm:[0,1,2,3] row_mask:%3 bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(vz[kq]) : "v"(u), "v"(inv), "n"(1 << kq));
+    a = WMF_MFMA16(u, vz[kq], a);
+    a[kr] = (eK != 0.f) ? -inv : a[kr];
+}
+template <int... Ks>
+__device__ __forceinline__ void gj_sweep_mfma(f32x4& a, int& pmin, std::integer_sequence<int, Ks...>) {
+    float vz[4] = {0.f, 0.f, 0.f, 0.f};
+    (gj_sweep_step_mfma<Ks>(a, pmin, vz), ...);
+}
+
 // value of lane (r, r >> 2) -- the same lane position in row group r >> 2 -- on every lane (r, q); hi8 / hi4: the lane masks
 // r >= 8, (r & 4) != 0 as 64-bit constants
 __device__ __forceinline__ float wmf_fetch_own_group(float v) {

@@ -99,7 +99,9 @@ __device__ __forceinline__ void gram_body6(const float* __restrict__ Y, int64_t 
     for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int last_col = min(16 * (NFB - 1) + r, ld - 1);
     const float col_mask_last = (16 * (NFB - 1) + r < f) ? 1.f : 0.f;
-    const int64_t row_lo = 4 * step_lo, row_hi = min(4 * step_hi, m);          // this wave's rows [row_lo, row_hi)
+    // chunks of 32 rows dealt round-robin over the waves (step_lo = this wave, step_hi = the number of waves): at any moment the
+    // resident waves read one contiguous stretch of the matrix
+    const int64_t row_lo = 32 * step_lo, row_hi = m, stride = 32 * step_hi;
     float cur[8][NFB], nxt[8][NFB];
     auto load_chunk = [&](int64_t c0, float (&fr)[8][NFB]) {
 #pragma unroll
@@ -112,8 +114,8 @@ __device__ __forceinline__ void gram_body6(const float* __restrict__ Y, int64_t 
         }
     };
     if (row_lo < row_hi) load_chunk(row_lo, cur);
-    for (int64_t c0 = row_lo; c0 < row_hi; c0 += 32) {
-        if (c0 + 32 < row_hi) load_chunk(c0 + 32, nxt);
+    for (int64_t c0 = row_lo; c0 < row_hi; c0 += stride) {
+        if (c0 + stride < row_hi) load_chunk(c0 + stride, nxt);
         gram_bf16x8 hi[NFB], mid[NFB], lo[NFB];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -129,20 +131,24 @@ __device__ __forceinline__ void gram_body6(const float* __restrict__ Y, int64_t 
                 hi[fb][j] = h; mid[fb][j] = md; lo[fb][j] = (__bf16)(r1 - (float)md);
             }
         }
-        int t = 0;
+        // product-major within a block row: consecutive MFMAs write different accumulators (six in a row on one tile wait
+        // for each other's result)
+        int t0 = 0;
 #pragma unroll
         for (int bi = 0; bi < NFB; ++bi) {
 #pragma unroll
-            for (int bj = bi; bj < NFB; ++bj, ++t) {
-                f32x4 c = acc[t];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo[bi], hi[bj], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[bi], mid[bj], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], lo[bj], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[bi], hi[bj], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], mid[bj], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], hi[bj], c, 0, 0, 0);
-                acc[t] = c;
-            }
+            for (int bj = bi; bj < NFB; ++bj) acc[t0 + bj - bi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo[bi], hi[bj], acc[t0 + bj - bi], 0, 0, 0);
+#pragma unroll
+            for (int bj = bi; bj < NFB; ++bj) acc[t0 + bj - bi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[bi], mid[bj], acc[t0 + bj - bi], 0, 0, 0);
+#pragma unroll
+            for (int bj = bi; bj < NFB; ++bj) acc[t0 + bj - bi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], lo[bj], acc[t0 + bj - bi], 0, 0, 0);
+#pragma unroll
+            for (int bj = bi; bj < NFB; ++bj) acc[t0 + bj - bi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid[bi], hi[bj], acc[t0 + bj - bi], 0, 0, 0);
+#pragma unroll
+            for (int bj = bi; bj < NFB; ++bj) acc[t0 + bj - bi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], mid[bj], acc[t0 + bj - bi], 0, 0, 0);
+#pragma unroll
+            for (int bj = bi; bj < NFB; ++bj) acc[t0 + bj - bi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[bi], hi[bj], acc[t0 + bj - bi], 0, 0, 0);
+            t0 += NFB - bi;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -159,12 +165,7 @@ __device__ __forceinline__ void gram_body6(const float* __restrict__ Y, int64_t 
 template <int NFB>
 __global__ __launch_bounds__(64) void gram6_kernel(const float* __restrict__ Y, int64_t m, int f, int ld, int bias,
                                                    float* __restrict__ partial, int64_t steps_per_wave) {
-    const int64_t nsteps = (m + 3) / 4;
-    int64_t lo = (int64_t)blockIdx.x * steps_per_wave;
-    int64_t hi = lo + steps_per_wave;
-    if (hi > nsteps) hi = nsteps;
-    if (lo > hi) lo = hi;
-    gram_body6<NFB>(Y, m, f, ld, bias, partial, lo, hi);
+    gram_body6<NFB>(Y, m, f, ld, bias, partial, blockIdx.x, gridDim.x);
 }
 
 template <int NFB, int NSPLIT>
@@ -254,6 +255,9 @@ int wmf_gram_nwaves(int64_t m, int f) {
     if (want < 1) want = 1;
     const int cap = wmf_gram_max_waves(f);
     if (want > cap) want = cap;
+    // every wave gets the same share of the rows up front, so the count is a whole number of waves per SIMD (256 CUs x 4):
+    // 1456 waves of the wide kernel (one resident wave per SIMD) ran as two rounds, the second 42 % full
+    if (want > 1024) want -= want % 1024;
     return (int)want;
 }
 
@@ -942,7 +946,10 @@ __global__ __launch_bounds__(512) void transform6_kernel(const float* __restrict
     };
     // one block of pieces at a time (two, as in transform_kernel, spill at 256 registers: the bf16 parts need room).  Two
     // 16-row blocks per trip sharing every B operand read (twelve MFMAs per three ds_read_b128 instead of six) were measured in
-    // round 2: 256 registers + 244 bytes of scratch at NFB = 9, 3.9 ms per cfg3 half step against 2.4.
+    // round 2: 256 registers + 244 bytes of scratch at NFB = 9, 3.9 ms per cfg3 half step against 2.4.  Requesting the next
+    // block's pieces into this block's registers chunk by chunk, as soon as each is split (no spill, a block of arithmetic
+    // between request and use): 2.25 against 2.06 ms for 10 M rows in the same process -- the two waves of a SIMD already
+    // cover each other's wait, and the kernel moves 5.1 TB/s.
     float4 xa[2 * NKC];
     for (int64_t blk = (int64_t)blockIdx.x * 8 + wv; blk < nblocks16; blk += stride) {
         request(blk, xa);

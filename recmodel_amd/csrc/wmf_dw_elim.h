@@ -32,6 +32,11 @@ __device__ __host__ constexpr int tile_off(int bi, int bj) {     // float offset
                              // five VALU instructions fewer a step, measured 19.49 against 19.26 ms at cfg3 (the permute's latency
                              // is not hidden when both waves of a SIMD sit in a sweep)
 #endif
+#ifndef WMF_DW_GJM
+#define WMF_DW_GJM 0         // 1: two-waves callers invert tiles by the symmetric sweep with f32 MFMA rank-one updates (wmf_common.h).
+                             // Measured 19.6 against 18.3 ms at cfg3: the f32 MFMA shares the VALU pipe (profiles/README.md), so its 32
+                             // cycles cost more than the eight VALU instructions it replaces
+#endif
 #ifndef WMF_DW_OPAQUE
 #define WMF_DW_OPAQUE 1
 #endif
@@ -134,7 +139,10 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
             // and vectors that still carry `diag`.
             if (diag != 1.f) X *= 1.f / diag;
             if constexpr (!GJ_LDS) {                                 // (the kernels whose wave runs alone on its SIMD)
-                if (!WMF_ABL(dbg, 8)) gj_inv_sweep_lean<(RELANE && WMF_DW_BP != 0)>(X, pmin, 4 * r, std::make_integer_sequence<int, 16>{});
+                if constexpr (RELANE && WMF_DW_GJM != 0) {
+                    gj_sweep_mfma(X, pmin, std::make_integer_sequence<int, 16>{});
+                    X = -X;
+                } else if (!WMF_ABL(dbg, 8)) gj_inv_sweep_lean<(RELANE && WMF_DW_BP != 0)>(X, pmin, 4 * r, std::make_integer_sequence<int, 16>{});
                 if (diag != 1.f) X *= 1.f / diag;
                 return X;
             }
