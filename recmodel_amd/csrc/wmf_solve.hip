@@ -47,9 +47,13 @@ __device__ __forceinline__ void gj_step(float (&m)[NSETS][NSETS * 4], float (&p)
         p[so] = fmaf(nf, pkv, p[so]);
     }
     {
-        float fk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(baddr[kq], __builtin_bit_cast(int, m[ks][kreg])));
-        fk = (r == kk) ? piv - 1.f : fk;
-        const float nf = -fk * inv;
+        const float fk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(baddr[kq], __builtin_bit_cast(int, m[ks][kreg])));
+        // nf = (e_K - f) / piv with e_K = [r == kk] as a constant lane mask shifted into place next to its use (three
+        // instructions where  r == kk ? piv - 1 : f  and the product take four; see gj_inv_step_lean, wmf_common.h)
+        float eK;
+        unsigned long long tmp;
+        asm volatile("s_lshl_b64 %1, %2, %3\n\tv_cndmask_b32 %0, 0, 1.0, %1" : "=v"(eK), "=&s"(tmp) : "s"(0x0001000100010001ull), "n"(kk));
+        const float nf = (eK - fk) * inv;
 #pragma unroll
         for (int c4 = 0; c4 < NSETS; ++c4)
             fmac_bcast4_self<kk>(m[ks][4 * c4], m[ks][4 * c4 + 1], m[ks][4 * c4 + 2], m[ks][4 * c4 + 3], nf);
