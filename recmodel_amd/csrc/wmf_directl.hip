@@ -574,7 +574,7 @@ int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const
     const dim3 grid((unsigned)(count < cap ? count : cap));
     const int dbg = wmf_debug_flags;
     const bool x6 = !(dbg & 8192);                              // debug flag 8192: f32 MFMA accumulation
-#define DL_LAUNCH(N, B, X) WMF_LAUNCH("solve_directl_kernel<" #N ", " #B ", " #X ">", (solve_directl_kernel<N, B, X>), grid, dim3(64), \
+#define DL_LAUNCH(N, B, X) WMF_LAUNCH("solve_directl_kernel<" #N ", " #B ", " #X ", 16, 0>", (solve_directl_kernel<N, B, X>), grid, dim3(64), \
                                       DL_LDSB(N, 16), st, rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, \
                                       (const int64_t*)nullptr, (const int32_t*)nullptr, (float*)nullptr)
 #define DL_PICK(N) do { if (f % 16) { if (x6) DL_LAUNCH(N, true, true); else DL_LAUNCH(N, true, false); } \
@@ -589,10 +589,10 @@ int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const
         // order, i.e. behind every LDS-DMA of the ring (27.3 ms with reloads of spilled lane constants inside the chunk loop,
         // 21.0 with none there, 19.9 with none at all); hipcc puts s_waitcnt vmcnt(0) in front of every LDS access it can see.
         const dim3 grid2((unsigned)(count < 2 * cap ? count : 2 * cap));
-        if (f % 16) WMF_LAUNCH("solve_directl_kernel<8, true, true, 8>", (solve_directl_kernel<8, true, true, 8>), grid2, dim3(64), DL_LDSB(8, 8), st,
+        if (f % 16) WMF_LAUNCH("solve_directl_kernel<8, true, true, 8, 0>", (solve_directl_kernel<8, true, true, 8>), grid2, dim3(64), DL_LDSB(8, 8), st,
                                rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, (const int64_t*)nullptr,
                                (const int32_t*)nullptr, (float*)nullptr);
-        else WMF_LAUNCH("solve_directl_kernel<8, false, true, 8>", (solve_directl_kernel<8, false, true, 8>), grid2, dim3(64), DL_LDSB(8, 8), st,
+        else WMF_LAUNCH("solve_directl_kernel<8, false, true, 8, 0>", (solve_directl_kernel<8, false, true, 8>), grid2, dim3(64), DL_LDSB(8, 8), st,
                         rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, (const int64_t*)nullptr,
                         (const int32_t*)nullptr, (float*)nullptr);
     } else DL_PICK(8);
