@@ -193,6 +193,29 @@ int wmf_coo_to_csr(const int64_t* rows, const int64_t* cols, const float* values
 /* values[i] = alpha*log(1+beta*values[i]) (mode 0) or alpha*values[i] (mode 1), in place on the
  * device.  wmf_model.py:119-123. */
 int wmf_confidence_transform(float* values, int64_t nnz, double alpha, double beta, int mode, void* stream);
+/* The same on float64 values (the count matrix of a `cores > 1` run stays float64, wmf_model.py:119-123). */
+int wmf_confidence_transform_f64(double* values, int64_t nnz, double alpha, double beta, int mode, void* stream);
+
+/* ---- float64 half step: the reference's Pool variants (a5 / a6) ------------------------------------------------------
+ * recompute_factors_par / recompute_factors_bias_par (wmf_model.py:242-265) and their row functions
+ * recompute_factors_intern / recompute_factors_bias_intern (:267-309): with a float64 count matrix every row is
+ *   x_u = solve(Y~^T Y~ + lambda I + Y~_u^T diag(w) Y~_u,  Y~_u^T (w + 1))        in float64,
+ * Y~ = Y with column 0 read as 1 and w = c_u - Y[idx, 0] for bias != 0 (:253-257, :279), rows without stored entries
+ * are zero (:274-276, :296-298), and the float64 rows are stacked without a cast (np.stack, :246 / :261) -- so the
+ * reference's `cores > 1` training continues on float64 factors.  This entry point is that arithmetic on the device,
+ * without the whitening of the float32 path: Gramian in float64, then per row LU with partial pivoting (np.linalg.solve
+ * is LAPACK gesv) carried in float64 -- the path for fidelity to those variants, one workgroup per row, not for speed.
+ *   Y [m, f] float64 row-major (dense, no padding), values float64[nnz], X [n, f] float64 out, all on the device;
+ *   workspace: wmf_half_step_f64_workspace_bytes(f, m, n) bytes; fail_count (device int32, caller zeroes): += 1 per
+ *   exactly singular row system (its X row is NaN; the reference raises LinAlgError).  Enqueues only. */
+int64_t wmf_half_step_f64_workspace_bytes(int f, int64_t m, int64_t n);
+int wmf_half_step_f64(const double* Y, int64_t m, int f, int bias, const int64_t* indptr, const int32_t* indices,
+                      const double* values, int64_t n, double lambda, double* X, void* workspace, int64_t workspace_bytes,
+                      int32_t* fail_count, void* stream);
+/* The same with host buffers in and out (what recompute_factors_par(Y, C, lambda_reg, cores) is handed, :242):
+ * synchronous, allocates and frees its device buffers; WMF_ENUMERIC if a row system was singular. */
+int wmf_recompute_factors_f64_host(const double* Y_host, int64_t m, int f, int bias, const int64_t* indptr,
+                                   const int32_t* indices, const double* values, int64_t n, double lambda, double* X_host);
 
 /* ---- partial systems for a reduce-scatter exchange (f <= 144) ------------------------------------
  * When the rows being updated are few and the fixed side is large (many users, few items), gathering the fixed

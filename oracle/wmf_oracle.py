@@ -190,8 +190,12 @@ def unweighted_half_steps(items_f, utility_mat, gamma, dim, dtype="float32"):
 # --------------------------------------------------------------------------- a2
 def train(num_items, num_users, dim, gamma, utility_mat, iterations, eval_mat, count_mat=None,
           weighted=True, bias=False, seed=1993, dtype="float32", alpha=10, stopping_rounds=3,
-          min_improvement=0.0001, pre_process_count="log", beta=1, preprocess_mat=False):
-    """``WMF(...).train(..., cores=1)`` as a function.  RecModel/wmf_model.py:49-189.
+          min_improvement=0.0001, pre_process_count="log", beta=1, preprocess_mat=False, cores=1):
+    """``WMF(...).train(...)`` as a function.  RecModel/wmf_model.py:49-189.
+
+    ``cores > 1`` (``:147-157``): the Pool variants stack their rows without the cast back to ``dtype``
+    (``:246``, ``:261``), so with a float64 count matrix the factors are float64 from the first half
+    step on and every later Gramian and row system is formed from float64 inputs.
 
     Returns ``(last_iter, mse_history, users, items)``.
     Early stopping (``:164-168,179-180``): the counter advances whenever
@@ -224,9 +228,10 @@ def train(num_items, num_users, dim, gamma, utility_mat, iterations, eval_mat, c
     C.data = confidence_transform(C.data, alpha, beta, pre_process_count)
     CT = C.T.tocsr()
     step = recompute_factors_bias if bias else recompute_factors
+    out_dtype = "float64" if cores > 1 and C.dtype == np.float64 else None
     for it in range(iterations):
-        users_f = step(items_f, C, gamma, dtype)
-        items_f = step(users_f, CT, gamma, dtype)
+        users_f = step(items_f, C, gamma, dtype, out_dtype)
+        items_f = step(users_f, CT, gamma, dtype, out_dtype)
         mse = eval_prec(users_f, items_f, eval_mat, bias)
         history.append(mse)
         stall = stall + 1 if mse * (1 + min_improvement) > last_mse else 0

@@ -50,6 +50,10 @@ SIGNATURES = {
     "wmf_coo_to_csr_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "wmf_coo_to_csr": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wmf_confidence_transform": (c_int, [c_vp, c_i64, c_dbl, c_dbl, c_int, c_vp]),
+    "wmf_confidence_transform_f64": (c_int, [c_vp, c_i64, c_dbl, c_dbl, c_int, c_vp]),
+    "wmf_half_step_f64_workspace_bytes": (c_i64, [c_int, c_i64, c_i64]),
+    "wmf_half_step_f64": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_dbl, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "wmf_recompute_factors_f64_host": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_dbl, c_vp]),
     "wmf_profile_enable": (c_int, [c_int]),
     "wmf_profile_set_tag": (c_int, [c_int]),
     "wmf_profile_collect": (c_int, []),

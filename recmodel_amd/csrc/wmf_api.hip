@@ -484,12 +484,76 @@ int wmf_confidence_transform(float* values, int64_t nnz, double alpha, double be
     return check_launch("wmf_confidence_transform");
 }
 
+int wmf_confidence_transform_f64(double* values, int64_t nnz, double alpha, double beta, int mode, void* stream) {
+    if ((!values && nnz > 0) || nnz < 0 || (mode != 0 && mode != 1)) { wmf_set_error("wmf_confidence_transform_f64: bad arguments"); return WMF_EINVAL; }
+    wmf_launch_confidence_f64(values, nnz, alpha, beta, mode, (hipStream_t)stream);
+    return check_launch("wmf_confidence_transform_f64");
+}
+
+// ---- float64 half step (the reference's cores > 1 variants) ---------------------------------------
+int64_t wmf_half_step_f64_workspace_bytes(int f, int64_t m, int64_t n) {
+    if (f < 1 || f > WMF_MAX_F || m < 0 || n < 0) return 0;
+    return wmf_f64_ws_bytes(f, m, n);
+}
+
+int wmf_half_step_f64(const double* Y, int64_t m, int f, int bias, const int64_t* indptr, const int32_t* indices,
+                      const double* values, int64_t n, double lambda, double* X, void* workspace, int64_t workspace_bytes,
+                      int32_t* fail_count, void* stream) {
+    if (f < 1 || f > WMF_MAX_F) { wmf_set_error("wmf_half_step_f64: f=%d unsupported", f); return WMF_EINVAL; }
+    if (!Y || !indptr || !workspace || !fail_count || m < 1 || n < 0 || (n > 0 && !X)) {
+        wmf_set_error("wmf_half_step_f64: null pointer or bad size"); return WMF_EINVAL;
+    }
+    if (workspace_bytes < wmf_f64_ws_bytes(f, m, n)) {
+        wmf_set_error("wmf_half_step_f64: workspace too small (need %lld bytes)", (long long)wmf_f64_ws_bytes(f, m, n)); return WMF_EINVAL;
+    }
+    wmf_launch_half_step_f64(Y, m, f, bias, indptr, indices, values, n, lambda, X, workspace, fail_count, (hipStream_t)stream);
+    return check_launch("wmf_half_step_f64");
+}
+
 // ---- host-level drop-in -------------------------------------------------------------------------
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : -1; }
 };
+
+int wmf_recompute_factors_f64_host(const double* Y_host, int64_t m, int f, int bias, const int64_t* indptr,
+                                   const int32_t* indices, const double* values, int64_t n, double lambda, double* X_host) {
+    if (!Y_host || !indptr || !X_host || m < 1 || n < 0 || f < 1 || f > WMF_MAX_F) {
+        wmf_set_error("wmf_recompute_factors_f64_host: bad arguments");
+        return WMF_EINVAL;
+    }
+    const int64_t nnz = indptr[n];
+    if (nnz > 0 && (!indices || !values)) { wmf_set_error("wmf_recompute_factors_f64_host: null CSR arrays"); return WMF_EINVAL; }
+    for (int64_t r = 0; r < n; ++r)
+        if (indptr[r + 1] < indptr[r]) { wmf_set_error("wmf_recompute_factors_f64_host: indptr not monotone at row %lld", (long long)r); return WMF_EINVAL; }
+    for (int64_t j = 0; j < nnz; ++j)
+        if (indices[j] < 0 || indices[j] >= m) { wmf_set_error("column index %d out of range at entry %lld", indices[j], (long long)j); return WMF_EINVAL; }
+    DevBuf dY, dPtr, dIdx, dVal, dX, dWs, dFail;
+    const int64_t wsb = wmf_f64_ws_bytes(f, m, n);
+    if (dY.alloc((size_t)m * f * 8) || dPtr.alloc((size_t)(n + 1) * 8) || dIdx.alloc((size_t)nnz * 4) || dVal.alloc((size_t)nnz * 8) ||
+        dX.alloc((size_t)(n > 0 ? n : 1) * f * 8) || dWs.alloc((size_t)wsb) || dFail.alloc(16)) {
+        wmf_set_error("wmf_recompute_factors_f64_host: device allocation failed");
+        return WMF_ENOMEM;
+    }
+    HIP_TRY(hipMemcpy(dY.p, Y_host, (size_t)m * f * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dPtr.p, indptr, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        HIP_TRY(hipMemcpy(dIdx.p, indices, (size_t)nnz * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dVal.p, values, (size_t)nnz * 8, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemset(dFail.p, 0, 16));
+    hipStream_t st = nullptr;
+    const int rc = wmf_half_step_f64((const double*)dY.p, m, f, bias, (const int64_t*)dPtr.p, (const int32_t*)dIdx.p,
+                                     (const double*)dVal.p, n, lambda, (double*)dX.p, dWs.p, wsb, (int32_t*)dFail.p, st);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    int32_t fail = 0;
+    HIP_TRY(hipMemcpy(&fail, dFail.p, 4, hipMemcpyDeviceToHost));
+    if (n > 0) HIP_TRY(hipMemcpy(X_host, dX.p, (size_t)n * f * 8, hipMemcpyDeviceToHost));
+    if (fail) { wmf_set_error("%d row systems were singular", fail); return WMF_ENUMERIC; }
+    return WMF_OK;
+}
 
 int wmf_recompute_factors_host(const float* Y_host, int64_t m, int f, int bias, const int64_t* indptr,
                                const int32_t* indices, const float* values, int64_t n, double lambda, float* X_host) {

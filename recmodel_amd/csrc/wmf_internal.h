@@ -115,6 +115,11 @@ int wmf_launch_rank_batch(const float* users, const float* items, int f, int ld,
                           const int32_t* cand, int64_t nc, int64_t topn, int32_t* out_pos, float* out_scores, void* ws,
                           int64_t ws_bytes, hipStream_t st);
 int wmf_launch_confidence(float* values, int64_t nnz, double alpha, double beta, int mode, hipStream_t st);
+// float64 half step of the cores > 1 variants (wmf_f64.hip)
+int64_t wmf_f64_ws_bytes(int f, int64_t m, int64_t n);
+int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const int64_t* indptr, const int32_t* indices,
+                             const double* values, int64_t n, double lambda, double* X, void* ws, int32_t* fail, hipStream_t st);
+int wmf_launch_confidence_f64(double* values, int64_t nnz, double alpha, double beta, int mode, hipStream_t st);
 
 void wmf_set_error(const char* fmt, ...);
 // Ablation switches whose results are WRONG (1 no elimination, 2 no accumulation MFMAs, 8 no tile inverse) are compiled

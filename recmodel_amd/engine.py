@@ -140,8 +140,21 @@ class HipKernels:
         return indptr, indices, values
 
     def confidence_transform(self, values, alpha, beta, mode):
+        if values.dtype == torch.float64:
+            _lib.check(self.lib.wmf_confidence_transform_f64(_ptr(values), values.numel(), float(alpha), float(beta), int(mode),
+                                                             _stream()))
+            return
         _lib.check(self.lib.wmf_confidence_transform(_ptr(values), values.numel(), float(alpha), float(beta), int(mode),
                                                      _stream()))
+
+    def half_step_f64_workspace_bytes(self, f, m, n):
+        return int(self.lib.wmf_half_step_f64_workspace_bytes(f, m, n))
+
+    def half_step_f64(self, Y, m, f, bias, indptr, indices, values, n, lam, X, ws, fail):
+        """One half step in float64 (the reference's cores > 1 variants, wmf_model.py:242-309): dense float64 [m, f] in,
+        dense float64 [n, f] out."""
+        _lib.check(self.lib.wmf_half_step_f64(_ptr(Y), m, f, int(bias), _ptr(indptr), _ptr(indices), _ptr(values), n, float(lam),
+                                              _ptr(X), _ptr(ws), ws.numel(), _ptr(fail), _stream()))
 
 
 class Csr:

@@ -1,10 +1,11 @@
 """``WMF``: weighted matrix factorisation by alternating least squares, on MI355X.
 
 Same class surface as RecModel/wmf_model.py:8-351 -- constructor, ``train`` / ``predict`` /
-``rank``, ``recompute_factors[_bias]``, public ``users`` / ``items`` host arrays -- with the
-numerical work done by libwmf_hip.so through ``AlsEngine``.  ``cores`` is accepted for
-compatibility (it selected a multiprocessing pool in the reference) and ignored beyond the
-reference's argument check.  There is no CPU fallback.
+``rank``, ``recompute_factors[_bias][_par]``, public ``users`` / ``items`` host arrays -- with the
+numerical work done by libwmf_hip.so through ``AlsEngine``.  ``cores`` selected a multiprocessing
+pool in the reference; what its Pool variants change numerically is the dtype -- float64 rows stacked
+without a cast -- and that is what ``cores > 1`` selects here too (the float64 device path,
+``wmf_half_step_f64``).  There is no CPU fallback.
 """
 import ctypes
 import time
@@ -22,6 +23,48 @@ def _csr_parts(mat):
     mat = scipy.sparse.csr_matrix(mat) if not scipy.sparse.isspmatrix_csr(mat) else mat
     return (torch.from_numpy(mat.indptr.astype(np.int64)), torch.from_numpy(mat.indices.astype(np.int64)),
             torch.from_numpy(mat.data.astype(np.float32)))
+
+
+class _Float64Steps:
+    """The two half steps of an iteration in float64 on the device (wmf_half_step_f64: RecModel/wmf_model.py:242-309) for
+    `train(cores > 1)` on a float64 count matrix.  Factors live here as dense float64 device tensors; after every iteration
+    float32 copies go to the engine, whose evaluation kernels compute the MSE train() stops on."""
+
+    def __init__(self, model, eng, count_mat, alpha, beta, pre_process_count):
+        self.eng, self.K, self.bias, self.gamma = eng, eng.K, bool(model.bias), float(model.gamma)
+        dev = eng.device
+        C = scipy.sparse.csr_matrix(count_mat)
+        self.csr = {}
+        for side, mat in (("users", C), ("items", C.T.tocsr())):       # the transpose as the reference takes it (:128)
+            vals = torch.from_numpy(np.ascontiguousarray(mat.data, dtype=np.float64)).to(dev)
+            self.K.confidence_transform(vals, alpha, beta, 0 if pre_process_count == 'log' else 1)
+            self.csr[side] = (torch.from_numpy(mat.indptr.astype(np.int64)).to(dev),
+                              torch.from_numpy(mat.indices.astype(np.int32)).to(dev), vals, mat.shape[0])
+        self.f = model.items.shape[1]
+        self.X = {"items": torch.from_numpy(np.ascontiguousarray(model.items, dtype=np.float64)).to(dev), "users": None}
+        n_max = max(C.shape)
+        self.ws = torch.empty(self.K.half_step_f64_workspace_bytes(self.f, n_max, n_max), dtype=torch.uint8, device=dev)
+        self.fail = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def _half(self, side, fixed):
+        indptr, indices, vals, n = self.csr[side]
+        Y = self.X[fixed]
+        out = torch.empty(n, self.f, dtype=torch.float64, device=Y.device)
+        self.K.half_step_f64(Y, Y.shape[0], self.f, self.bias, indptr, indices, vals, n, self.gamma, out, self.ws, self.fail)
+        self.X[side] = out
+
+    def iteration(self):
+        self._half("users", "items")
+        self._half("items", "users")
+        fail = int(self.fail[0])
+        if fail:
+            self.fail.zero_()
+            raise _lib.WmfNumericError(f"{fail} row systems were singular")
+        for side in ("users", "items"):
+            self.eng.set_factors(side, self.X[side].to(torch.float32))
+
+    def factors(self):
+        return self.X["users"].cpu().numpy(), self.X["items"].cpu().numpy()
 
 
 class WMF(RecModel):
@@ -207,6 +250,32 @@ class WMF(RecModel):
         """Bias variant: column 0 of Y is the fixed side's bias.  wmf_model.py:311-351."""
         return self._recompute(Y, C, lambda_reg, 1)
 
+    # ------------------------------------------------------------------ a5 / a6: the Pool variants
+    def recompute_factors_par(self, Y, C, lambda_reg, cores=4):
+        """wmf_model.py:242-250 (+ :289-309): the rows are independent, so `cores` has nothing to distribute here; what the
+        variant changes is the dtype -- float64 rows stacked without a cast when Y or C is float64."""
+        return self._recompute_par(Y, C, lambda_reg, 0)
+
+    def recompute_factors_bias_par(self, Y, C, lambda_reg, cores=3):
+        """wmf_model.py:252-265 (+ :267-287).  Column 0 of Y is the fixed side's bias (the caller's array is not modified)."""
+        return self._recompute_par(Y, C, lambda_reg, 1)
+
+    def _recompute_par(self, Y, C, lambda_reg, bias):
+        C = scipy.sparse.csr_matrix(C)
+        if np.result_type(np.asarray(Y).dtype, C.dtype) != np.float64:
+            return self._recompute(Y, C, lambda_reg, bias)            # all-float32 inputs: float32 rows, as in the reference
+        _lib.require_gpu()
+        lib = _lib.load()
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        indptr = np.ascontiguousarray(C.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(C.indices, dtype=np.int32)
+        values = np.ascontiguousarray(C.data, dtype=np.float64)
+        X = np.empty((C.shape[0], Y.shape[1]), dtype=np.float64)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        _lib.check(lib.wmf_recompute_factors_f64_host(vp(Y), Y.shape[0], Y.shape[1], bias, vp(indptr), vp(indices),
+                                                      vp(values), C.shape[0], float(lambda_reg), vp(X)))
+        return X
+
     def _recompute(self, Y, C, lambda_reg, bias):
         _lib.require_gpu()
         lib = _lib.load()
@@ -293,6 +362,10 @@ class WMF(RecModel):
         values = values.to(eng.device)
         eng.K.confidence_transform(values, alpha, beta, 0 if pre_process_count == 'log' else 1)
         eng.set_interactions(indptr, indices, values)      # also builds the item-major shard (:128)
+        # cores > 1 with a float64 count matrix: the reference's Pool variants keep float64 rows (:242-265), so its
+        # training continues on float64 factors -- the float64 device path then does the half steps, the engine only the MSE
+        f64 = _Float64Steps(self, eng, count_mat, alpha, beta, pre_process_count) \
+            if cores > 1 and np.dtype(count_mat.dtype) == np.float64 else None
         eval_shard = self._train_eval_shard(eng, eval_mat)
         train_shard = eng.make_eval_shard(*_csr_parts(utility_mat)) if verbose > 1 else None
 
@@ -300,9 +373,12 @@ class WMF(RecModel):
             if verbose > 0:
                 print(f"Starting fitting iteration {iter}")
             start = time.time()
-            eng.half_step("users")
-            eng.half_step("items")
-            eng.check_numerics()
+            if f64 is not None:
+                f64.iteration()
+            else:
+                eng.half_step("users")
+                eng.half_step("items")
+                eng.check_numerics()
             if self.bias is True and cores == 1:
                 print(f"Iteration {iter} took {round(time.time() - start, 4)} seconds.")
             mse_eval = self._mse(eng, eval_shard)
@@ -318,12 +394,11 @@ class WMF(RecModel):
                 print(f"\tMSE Train: {self._mse(eng, train_shard)}")
             if count_improvement >= stopping_rounds:
                 break
-        self._pull(eng)
-        if cores > 1:
-            # dtype quirk of the reference: its Pool variants (wmf_model.py:242-265) stack float64 row results
-            # without the cast back to self.dtype.  Values are the float32 results, widened.
-            self.users, self.items = self.users.astype(np.float64), self.items.astype(np.float64)
+        if f64 is not None:
+            self.users, self.items = f64.factors()          # float64, as the reference's Pool variants leave them
             self._freeze()
+        else:
+            self._pull(eng)
         if verbose > 0:
             print("Training was completed.")
         if verbose > 1:

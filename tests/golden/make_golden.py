@@ -197,5 +197,31 @@ def main():
             print(f, os.path.getsize(f"{OUT}/{f}"))
 
 
+def make_train_par(WMF):
+    """a5 / a6 inside train(): cores = 2 on a float64 count matrix -- the Pool variants leave float64 factors, so every
+    half step after the first runs on float64 inputs (wmf_model.py:147-157, :242-265)."""
+    counts = make_counts(120, 60, 5, seed=51, dtype="float64")
+    util = counts.copy()
+    util.data = np.minimum(util.data, 5.0)
+    out = {}
+    for bias in (False, True):
+        mdl = WMF(num_items=60, num_users=120, dim=8, gamma=0.1, weighted=True, bias=bias, seed=1993)
+        # (no per-iteration recorder on the instance here: Pool pickles the bound row function and the model with it)
+        last = mdl.train(utility_mat=util, iterations=3, verbose=0, eval_mat=util, count_mat=counts, cores=2,
+                         stopping_rounds=5)
+        assert mdl.users.dtype == np.float64 and mdl.items.dtype == np.float64
+        out[f"last_iter_bias{int(bias)}"] = last
+        out[f"mse_final_bias{int(bias)}"] = mdl.eval_prec(util)
+        out[f"users_bias{int(bias)}"] = mdl.users
+        out[f"items_bias{int(bias)}"] = mdl.items
+    out.update(csr_fields("counts", counts))
+    out.update(csr_fields("util", util))
+    np.savez_compressed(f"{OUT}/train_par.npz", **out)
+    print("train_par.npz", os.path.getsize(f"{OUT}/train_par.npz"))
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["train_par"]:                    # only the file added in round 2 (the others stay byte-identical)
+        make_train_par(load_reference())
+        sys.exit(0)
     main()

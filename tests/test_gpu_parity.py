@@ -391,6 +391,69 @@ def test_full_training_vs_oracle(WMF):
         assert np.mean(overlap) >= 0.99
 
 
+# ------------------------------------------------------------------ a5 / a6: the Pool variants in float64
+def test_pool_variants_float64_vs_reference_golden_and_oracle(WMF):
+    """recompute_factors_par / recompute_factors_bias_par (wmf_model.py:242-309) through wmf_recompute_factors_f64_host:
+    float64 rows against the reference's own outputs (golden half_par.npz; its first Gramian is a float32 product, so 1e-5)
+    and against the float64 oracle fed float64 inputs (the arithmetic itself: 1e-10)."""
+    g = load_golden("half_par.npz")
+    C = csr_from(g, "C")
+    assert C.dtype == np.float64
+    for bias in (False, True):
+        Y, ref = g[f"items0_bias{int(bias)}"], g[f"users_par_bias{int(bias)}"]
+        model = WMF(num_items=30, num_users=40, dim=8, gamma=0.1, weighted=True, bias=bias)
+        fn = model.recompute_factors_bias_par if bias else model.recompute_factors_par
+        Y_in = Y.copy()
+        got = fn(Y_in, C, 0.1, cores=2)
+        assert got.dtype == np.float64 and got.shape == ref.shape
+        assert np.array_equal(Y_in, Y)                                   # the caller's factors are left alone
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
+        step = orc.recompute_factors_bias if bias else orc.recompute_factors
+        want = step(Y.astype(np.float64), C, 0.1, dtype="float64")
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-13)
+        empty = np.flatnonzero(np.diff(C.indptr) == 0)
+        assert len(empty) and np.all(got[empty] == 0)                    # rows without stored entries: zeros (:274-276, :296-298)
+        got32 = fn(Y, C.astype(np.float32), 0.1, cores=2)                # all-float32 inputs stay float32 in the reference
+        assert got32.dtype == np.float32 and fro(got32, ref) <= HALF_FRO
+
+
+@pytest.mark.parametrize("k,bias", [(16, False), (64, True), (128, True), (256, False)])
+def test_float64_half_step_all_degree_classes(WMF, k, bias):
+    """The float64 device path on the ragged matrix of the float32 tests (degrees 0 ... full row, a stored zero, a
+    duplicate) at narrow and wide f, and -- bias -- with weights that go negative (LU with partial pivoting, as gesv)."""
+    n, m_items = 120, 150
+    C = as_f64(ragged_matrix(n, m_items, seed=5 + k))
+    model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=bias)
+    Y = model.items.astype(np.float64)
+    if bias:
+        Y[:, 0] = np.linspace(-5, 30, m_items)                            # about a third of the weights go negative
+    fn = model.recompute_factors_bias_par if bias else model.recompute_factors_par
+    got = fn(Y, C, 0.1)
+    want = (orc.recompute_factors_bias if bias else orc.recompute_factors)(Y, C, 0.1, dtype="float64")
+    assert got.dtype == np.float64 and not np.isnan(got).any()
+    ok = np.linalg.norm(want, axis=1) < 1e3                               # indefinite rows can be near singular themselves
+    assert ok.mean() > 0.9
+    assert fro(got[ok], want[ok]) <= 1e-8
+    assert np.all(got[0] == 0)                                            # the empty row
+
+
+def test_train_cores2_float64_vs_reference_golden(WMF):
+    """train(cores=2) on a float64 count matrix against the reference's own run (golden train_par.npz) and the oracle."""
+    g = load_golden("train_par.npz")
+    counts, util = csr_from(g, "counts"), csr_from(g, "util")
+    for bias in (False, True):
+        model = WMF(num_items=util.shape[1], num_users=util.shape[0], dim=8, gamma=0.1, weighted=True, bias=bias)
+        last = model.train(utility_mat=util, iterations=3, eval_mat=util, count_mat=counts, cores=2, stopping_rounds=5)
+        assert last == int(g[f"last_iter_bias{int(bias)}"])
+        assert model.users.dtype == np.float64 and model.items.dtype == np.float64
+        assert fro(model.users, g[f"users_bias{int(bias)}"]) <= 2e-5 and fro(model.items, g[f"items_bias{int(bias)}"]) <= 2e-5
+        assert abs(model.eval_prec(util) - float(g[f"mse_final_bias{int(bias)}"])) <= 1e-5 * float(g[f"mse_final_bias{int(bias)}"])
+    # a float32 count matrix keeps the reference's Pool variants in float32
+    model = WMF(num_items=util.shape[1], num_users=util.shape[0], dim=8, gamma=0.1, weighted=True)
+    model.train(utility_mat=util, iterations=1, eval_mat=util, count_mat=counts.astype(np.float32), cores=2, stopping_rounds=5)
+    assert model.users.dtype == np.float32
+
+
 def test_train_argument_errors_like_reference(WMF):
     c = sp.random(30, 20, density=0.3, format="csr", random_state=1)
     m = WMF(num_items=20, num_users=30, dim=4, gamma=0.1, weighted=True)

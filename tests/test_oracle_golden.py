@@ -52,6 +52,22 @@ def test_pool_variants_are_float64_and_equal_serial():
         np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12)
 
 
+def test_train_with_pool_variants_keeps_float64_factors():
+    """train(cores=2) on a float64 count matrix: golden from the reference itself (tests/golden/make_golden.py train_par)."""
+    g = load_golden("train_par.npz")
+    counts, util = csr_from(g, "counts"), csr_from(g, "util")
+    for bias in (False, True):
+        last, hist, users, items = orc.train(
+            num_items=util.shape[1], num_users=util.shape[0], dim=8, gamma=0.1, utility_mat=util, iterations=3,
+            eval_mat=util, count_mat=counts, weighted=True, bias=bias, stopping_rounds=5, cores=2)
+        assert users.dtype == np.float64 and items.dtype == np.float64
+        assert last == int(g[f"last_iter_bias{int(bias)}"])
+        # the first Gramian is taken of float32 factors in float32 (BLAS order unknown): 1e-6, not 1e-12
+        np.testing.assert_allclose(users, g[f"users_bias{int(bias)}"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(items, g[f"items_bias{int(bias)}"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(hist[-1], g[f"mse_final_bias{int(bias)}"], rtol=1e-6)
+
+
 @pytest.mark.parametrize("tag,bias", [("run", False), ("stop", False), ("bias", True)])
 def test_train_control_flow_predict_rank(tag, bias):
     g = load_golden(f"train_{tag}.npz")
