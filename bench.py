@@ -412,10 +412,11 @@ def main():
         "ms_per_step": main_res.pop("ms_per_step"), "higher_is_better": True,
         "scaling": scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "precision_note": "float32 storage, float32 accumulation everywhere; Gramian fp64 across waves; where a kernel is "
-                          "MFMA-bound its products are three-way bf16 splits of the float32 operands (six bf16 MFMAs per tile, "
-                          "every product exact, result within 1.4x of the f32-MFMA error: DESIGN.md section 5); parity tolerance "
-                          "unchanged (tests/test_gpu_parity.py)",
+        "precision_note": "float32 storage, float32 accumulation everywhere; Gramian fp64 across waves; the GEMM-shaped "
+                          "products run on f16 / bf16 MFMAs from SPLIT float32 operands: whitened rows (|v| <= 1) as two f16 "
+                          "parts (22 bits, three MFMAs per tile, every product exact in f32), factor matrices in the Gramian and "
+                          "the row transforms as three bf16 parts (exact split, six MFMAs per tile); results within 1.4x of the "
+                          "f32-MFMA error (DESIGN.md section 5); parity tolerance unchanged (tests/test_gpu_parity.py)",
     }
     cpu = main_res.pop("cpu_baseline", None)
     out.update(main_res)
