@@ -575,6 +575,27 @@ def test_accumulate_then_eliminate_equals_the_row_solve(k, bias):
     assert not a[0].any()                                          # the row without entries
 
 
+@pytest.mark.parametrize("m,f,bias", [(200_003, 129, 1), (300_001, 128, 0), (140_000, 64, 0), (131, 129, 1)])
+def test_gramian_at_wave_count_boundaries(m, f, bias):
+    """The Gramian kernels deal 32-row chunks (wide factors) or row ranges over a wave count that is rounded to a whole number of
+    waves per SIMD above 1024: sizes just past that rounding, a ragged last chunk, and fewer rows than one chunk per wave."""
+    from recmodel_amd import _lib
+    from recmodel_amd.engine import _ptr, _stream
+    lib = _lib.load()
+    ld = lib.wmf_ld_for(f)
+    g = torch.Generator(device="cuda").manual_seed(m)
+    Yd = torch.zeros(m, ld, device="cuda")
+    Yd[:, :f] = torch.randn(m, f, device="cuda", generator=g)
+    ws = torch.empty(int(lib.wmf_gram_workspace_bytes(f)), dtype=torch.uint8, device="cuda")
+    G = torch.zeros(f * f, dtype=torch.float64, device="cuda")
+    _lib.check(lib.wmf_gram(_ptr(Yd), m, f, ld, bias, _ptr(G), _ptr(ws), _stream()))
+    Yt = Yd[:, :f].double()
+    if bias:
+        Yt[:, 0] = 1
+    Gref = (Yt.T @ Yt).cpu().numpy()
+    np.testing.assert_allclose(G.cpu().numpy().reshape(f, f), Gref, rtol=0, atol=2e-6 * np.abs(Gref).max())
+
+
 def test_device_building_blocks_individually():
     """gram / factorize / row_transform against NumPy, including a non-positive-definite Gramian."""
     from recmodel_amd import _lib
