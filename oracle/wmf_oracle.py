@@ -62,6 +62,18 @@ def solve_row(G, Y, idx, w):
     return np.linalg.solve(A, b)
 
 
+def solve_row_in_slabs(G, slabs):
+    """``solve_row`` for a row too long to gather at once (a power-law head with millions of stored entries): the same
+    two sums of RecModel/wmf_model.py:237-239, ``A = G + sum_s U_s^T diag(w_s) U_s`` and ``b = sum_s (w_s + 1)^T U_s``,
+    taken over consecutive slabs ``(U_s, w_s)`` of the row's gathered factors, then the same LU solve."""
+    A = np.array(G, dtype=np.float64, copy=True)
+    b = np.zeros(A.shape[0], dtype=np.float64)
+    for U, w in slabs:
+        A += np.dot(U.T, U * w[:, np.newaxis])
+        b += np.dot(w + 1, U)
+    return np.linalg.solve(A, b)
+
+
 def recompute_factors(Y, C, lam, dtype="float32", out_dtype=None):
     """No-bias half step.  RecModel/wmf_model.py:213-240.
 

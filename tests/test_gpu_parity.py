@@ -15,7 +15,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from conftest import csr_from, load_golden
+from conftest import csr_from, load_golden, record_error
 from oracle import wmf_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -250,6 +250,7 @@ def test_half_step_vs_oracle_all_degree_classes(WMF, k, bias):
         got = step_g(Y, mat, 0.1)
         rel, zero_abs = worst_row(got, want)
         tol_fro, tol_row = (HALF_FRO, HALF_ROW) if k + bias <= 144 else (WIDE_FRO, WIDE_ROW)
+        record_error(f"degree_classes[k={k},bias={int(bias)}] {'users' if mat is C else 'items'}", worst_row=rel, fro=fro(got, want))
         assert fro(got, want) <= tol_fro, (k, bias, fro(got, want))
         assert rel <= tol_row and zero_abs == 0.0, (k, bias, rel, zero_abs)
         assert not np.isnan(got).any()
@@ -337,7 +338,10 @@ def test_many_heavy_rows_per_wave_at_k128(WMF, bias):
     # the two kernels differ in arithmetic (split-f16 products with an LDS-DMA ring here, f32 MFMAs from a register ring
     # there): they agree to the accuracy either has against the oracle, far inside the row tolerance
     rel = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
-    assert rel.max() <= 0.2 * HALF_ROW, (rel.max(), int(rel.argmax()), int(deg[rel.argmax()]))
+    record_error(f"heavy_rows_k128[bias={int(bias)}]", worst_row_vs_oracle=rel_o, fro_vs_oracle=fro(got, want),
+                 split_f16_vs_f32_kernel_worst_row=rel.max())
+    # (measured: 3.5e-7 worst row -- the one check that isolates the split-f16 arithmetic)
+    assert rel.max() <= 2e-6, (rel.max(), int(rel.argmax()), int(deg[rel.argmax()]))
     Yt, bvec = Y.astype(np.float64).copy(), np.zeros(m_items)
     if bias:
         bvec, Yt[:, 0] = Yt[:, 0].copy(), 1.0
@@ -347,6 +351,71 @@ def test_many_heavy_rows_per_wave_at_k128(WMF, bias):
         U, w = Yt[C.indices[lo:hi]], C.data[lo:hi].astype(np.float64) - bvec[C.indices[lo:hi]]
         A, b = G + U.T @ (U * w[:, None]), (w + 1) @ U
         assert np.linalg.norm(A @ got[u] - b) <= 2e-5 * np.linalg.norm(b)
+
+
+def _weight_range_matrix(n, m_items, rng, mode):
+    """Every degree class (0, 1, 8, 9, 16, 17, 32, 33, 100, 400, 5000 = segments) under confidence weights far from the bench's
+    10 log(1 + c) in [7, 19]: 'linear' pre-processing of large counts (alpha * c up to 1e6, wmf_model.py:122-123), tiny
+    weights down to 1e-3, both in one row; mode 'overflow' adds entries whose sqrt(w) |v| is beyond the f16 range."""
+    degs = [0, 1, 8, 9, 16, 17, 32, 33, 100, 400, 5000, 31, 64, 7] + [int(x) for x in rng.integers(1, 120, n - 14)]
+    degs = [min(d, m_items) for d in degs]
+    indptr = np.concatenate([[0], np.cumsum(degs)])
+    indices = np.concatenate([np.sort(rng.choice(m_items, d, replace=False)) for d in degs if d]).astype(np.int32)
+    z = int(indptr[-1])
+    kind = rng.integers(0, 4, z)
+    counts = np.where(kind == 0, rng.integers(1, 6, z), np.where(kind == 1, 10.0 ** rng.integers(1, 6, z), 1.0))
+    w = np.where(kind == 0, 10 * np.log(1 + counts), 10.0 * counts)                      # 'log' next to 'linear'
+    if mode != "bias":
+        w = np.where(kind == 2, 10.0 ** rng.uniform(-3, 0, z), w)                        # tiny weights
+    if mode == "overflow":
+        hot = rng.random(z) < 0.01
+        hot[indptr[8]] = hot[indptr[10] + 5] = True                                      # in a heavy and in a segmented row for sure
+        w = np.where(hot, 10.0 ** rng.uniform(11, 13, z), w)
+    return sp.csr_matrix((w.astype(np.float32), indices, indptr), shape=(n, m_items)), np.array(degs)
+
+
+@pytest.mark.parametrize("k,bias,mode", [(64, False, "wide"), (64, True, "bias"), (128, False, "wide"), (128, True, "bias"),
+                                         (256, False, "wide"), (256, True, "bias"),
+                                         (64, False, "overflow"), (128, False, "overflow"), (128, True, "overflow"), (256, False, "overflow")])
+def test_weight_range_of_the_class_surface(WMF, k, bias, mode):
+    """The class surface admits any confidence weight (pre_process_count='linear' on raw counts, wmf_model.py:122-123), the
+    split-f16 kernels scale operands by sqrt(w): weights from 1e-3 to 1e6 over every degree class must stay inside the stated
+    tolerance wherever the reference's own float32 arithmetic does, and a row is never worse than 4 x what NumPy's float32
+    restatement of the same row (the reference with a float32 count matrix) is against the float64 oracle.  'overflow': a few
+    weights of 1e11 .. 1e13 whose scaled operands leave the f16 range -- those rows must come back finite and as good as
+    that, through the pivoted kernel."""
+    rng = np.random.default_rng(1000 + k + bias)
+    n, m_items = 300, 6000
+    C, degs = _weight_range_matrix(n, m_items, rng, mode)
+    model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=bias)
+    Y = model.items.copy()
+    if bias:
+        Y[:, 0] *= 0.5                                                # weights >= 1 stay positive
+    step_o = orc.recompute_factors_bias if bias else orc.recompute_factors
+    step_g = model.recompute_factors_bias if bias else model.recompute_factors
+    want = step_o(Y, as_f64(C), 0.1, out_dtype="float64")
+    ref32 = np.full(want.shape, np.inf)                                # the reference's arithmetic on float32 counts, row by row
+    for r in range(n):                                                #   (a row whose float32 system is singular stays inf)
+        one = sp.csr_matrix((C.data[C.indptr[r]: C.indptr[r + 1]], C.indices[C.indptr[r]: C.indptr[r + 1]],
+                             [0, C.indptr[r + 1] - C.indptr[r]]), shape=(1, m_items))
+        try:
+            ref32[r] = step_o(Y, one, 0.1)[0]
+        except np.linalg.LinAlgError:
+            pass
+    got = step_g(Y, C, 0.1).astype(np.float64)
+    assert np.isfinite(got).all()
+    den = np.linalg.norm(want, axis=1)
+    ok = den > 0
+    e_got = np.linalg.norm(got - want, axis=1)[ok] / den[ok]
+    with np.errstate(invalid="ignore"):
+        e_ref = np.nan_to_num(np.linalg.norm(ref32 - want, axis=1)[ok] / den[ok], nan=np.inf, posinf=np.inf)
+    tol_row = HALF_ROW if k + bias <= 144 else WIDE_ROW
+    bad = e_got > np.maximum(tol_row, 4 * e_ref)
+    record_error(f"weight_range[k={k},bias={int(bias)},{mode}]", worst_row=e_got.max(), worst_row_numpy_f32=e_ref.max(),
+                 median_row=float(np.median(e_got)), median_row_numpy_f32=float(np.median(e_ref)),
+                 rows_above_tolerance=int((e_got > tol_row).sum()), rows_numpy_f32_above_tolerance=int((e_ref > tol_row).sum()))
+    assert not bad.any(), (k, bias, mode, int(bad.sum()), e_got[bad][:5], e_ref[bad][:5], degs[ok][bad][:5])
+    assert not got[degs == 0].any()
 
 
 @pytest.mark.parametrize("k", [16, 64, 128, 256])       # 128: the split-bf16 heavy-row kernel (a negative weight has no square root there)

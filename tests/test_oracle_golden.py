@@ -152,3 +152,15 @@ def test_eval_topn_matches_reference_golden(bias):
     assert hits.sum() > 0 and (np.diff(hits) >= 0).all()          # Recall@1 <= Recall@5 <= Recall@10
     with pytest.raises(ValueError):
         orc.eval_topn(g["users"], g["items"], test, [1, 5], rand_sampled=40)
+
+
+def test_solve_row_in_slabs_equals_solve_row():
+    """The slab form used for power-law heads at full size (tests/test_gpu_scale.py) is solve_row's arithmetic."""
+    rng = np.random.default_rng(3)
+    Y = rng.random((500, 12))
+    G = orc.gramian(Y, 0.1, "float64")
+    idx = rng.choice(500, 333, replace=False)
+    w = rng.random(333) * 20
+    want = orc.solve_row(G, Y, idx, w)
+    slabs = [(Y[idx[lo: lo + 100]], w[lo: lo + 100]) for lo in range(0, 333, 100)]
+    np.testing.assert_allclose(orc.solve_row_in_slabs(G, slabs), want, rtol=1e-12, atol=1e-14)
