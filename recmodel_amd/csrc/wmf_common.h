@@ -264,7 +264,8 @@ __device__ __forceinline__ void gj_inv_step_lean(f32x4& a, int& pmin, int r4 = 0
                  "s_lshl_b64 %2, 0xffff, %6\n\t"
                  "v_cndmask_b32 %1, %3, %0, %2"
                  : "=&v"(eK), "=v"(pre), "=&s"(tmp)
-                 : "v"(akr), "s"(0x0001000100010001ull), "n"(K), "n"(16 * kq));
+                 : "v"(akr), "s"(0x0001000100010001ull), "n"(K), "n"(16 * kq)
+                 : "scc");                                           // s_lshl_b64 writes SCC
     a[kr] = pre;
     const float nf = (eK - fk) * inv;
     float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
@@ -295,7 +296,7 @@ __device__ __forceinline__ void gj_sweep_step_mfma(f32x4& a, int& pmin, float (&
     const float inv = __builtin_amdgcn_rcpf(piv);
     float eK;                                                    // 1 in lane (K, K / 4), 0 elsewhere
     unsigned long long tmp;
-    asm volatile("s_lshl_b64 %1, 1, %2\n\tv_cndmask_b32 %0, 0, 1.0, %1" : "=v"(eK), "=&s"(tmp) : "n"(K + 16 * kq));
+    asm volatile("s_lshl_b64 %1, 1, %2\n\tv_cndmask_b32 %0, 0, 1.0, %1" : "=v"(eK), "=&s"(tmp) : "n"(K + 16 * kq) : "scc");
     const float u = akr - eK;
     // (two wait states between the VALU write of u and the DPP read, two between the write of v and the MFMA: hipcc keeps
     // neither around an asm block)

@@ -52,7 +52,7 @@ __device__ __forceinline__ void gj_step(float (&m)[NSETS][NSETS * 4], float (&p)
         // instructions where  r == kk ? piv - 1 : f  and the product take four; see gj_inv_step_lean, wmf_common.h)
         float eK;
         unsigned long long tmp;
-        asm volatile("s_lshl_b64 %1, %2, %3\n\tv_cndmask_b32 %0, 0, 1.0, %1" : "=v"(eK), "=&s"(tmp) : "s"(0x0001000100010001ull), "n"(kk));
+        asm volatile("s_lshl_b64 %1, %2, %3\n\tv_cndmask_b32 %0, 0, 1.0, %1" : "=v"(eK), "=&s"(tmp) : "s"(0x0001000100010001ull), "n"(kk) : "scc");
         const float nf = (eK - fk) * inv;
 #pragma unroll
         for (int c4 = 0; c4 < NSETS; ++c4)
