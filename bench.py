@@ -157,7 +157,8 @@ def kernel_work(name, csr, eng, side):
         # is bound by that read
         if name.startswith("gram6"):
             return "hbm", 4.0 * f * eng.n_local[fixed]
-        return "mfma", 2.0 * f * f * eng.n_local[fixed]
+        # (the kernel forms the upper 16 x 16 tiles only: f (f + 1) multiply-adds per row, not 2 f^2)
+        return "mfma", 1.0 * f * (f + 1) * eng.n_local[fixed]
     return None
 
 
@@ -185,7 +186,8 @@ def traffic_of(table, name, side, both_sides):
     return k.get("hbm_bytes_mean_corrected")
 
 
-def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu):
+def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu, zipf=None):
+    zipf = args.zipf if zipf is None else float(zipf)
     n_users_1, n_items, dbar, k, bias = synth.CONFIGS[cfg_name]
     n_users = n_users_1 * world if scaling == "weak" else n_users_1
     gamma = 0.1
@@ -201,7 +203,7 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu):
     per_block = n_users // nb
     my_blocks = range(rank * nb // world, (rank + 1) * nb // world)
     parts = [synth.make_counts(per_block if b < nb - 1 else n_users - per_block * (nb - 1), n_items, dbar, seed, device=dev,
-                               zipf_a=args.zipf, first_user=b * per_block) for b in my_blocks]
+                               zipf_a=zipf, first_user=b * per_block) for b in my_blocks]
     first_user = my_blocks[0] * per_block
     ptrs, offset = [parts[0][0][:1]], 0
     for ip_b, _, _ in parts:
@@ -317,10 +319,19 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu):
         torch.distributed.all_reduce(eb)
         epoch_bytes = float(eb.item())
 
+    if roofline is not None:                       # (the driver's record keeps "roofline" whole and drops keys it does not know)
+        roofline["user_solve"] = half["users"]
+        roofline["item_solve"] = half["items"]
+    nnz_mine = torch.tensor([eng.csr["users"].nnz], dtype=torch.int64, device=dev)
+    per_rank_nnz = [int(nnz_mine.item())]
+    if world > 1:
+        gathered = [torch.zeros_like(nnz_mine) for _ in range(world)]
+        torch.distributed.all_gather(gathered, nnz_mine)
+        per_rank_nnz = [int(t.item()) for t in gathered]
     out = {
         "value": (n_users + n_items) * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
         "config": {"workload": f"{cfg_name}: WMF k={k}{'+bias' if bias else ''}, {n_users}x{n_items} CSR, "
-                               f"{nnz} nnz, alpha-log confidence, gamma={gamma}, zipf_a={args.zipf}",
+                               f"{nnz} nnz, alpha-log confidence, gamma={gamma}, zipf_a={zipf}",
                    "n_users": n_users, "n_items": n_items, "nnz": nnz, "k": k, "bias": bias,
                    "sharding": f"users+items dealt by cost (nnz f^2 + f^3) over {world} GPU(s), every rank loads 1/{world} of the user "
                                f"rows; exchange users: "
@@ -336,6 +347,9 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu):
         "kernels": kernels,
         "eval": {"ms": t_eval * 1e3, "mse": sq / cnt if cnt else None},
         "setup_s": t_setup,
+        "ranks": {"world_size": (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
+                  "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
+                  "nnz_of_the_user_shard_per_rank": per_rank_nnz},
         "row_bins": {s: {"rows": eng.csr[s].bin_rows.tolist(), "nnz": eng.csr[s].bin_nnz.tolist(),
                          "rows_le8": eng.csr[s].rows8, "rows_split": eng.csr[s].rows_split} for s in SIDES},
     }
@@ -354,11 +368,61 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu):
         else:                                                    # timing does not depend on the values
             users_f = np.random.default_rng(0).random((n_users, eng.f), dtype=np.float32)
         out["cpu_baseline"] = cpu_baseline(cfg_name, user_rows, item_rows, users_f, k, bias, gamma, n_items)
+        if n_users > 2_000_000:
+            out["cpu_baseline"]["note"] = ("the item-rows leg runs against RANDOM user factors (uniform [0, 1), same shape): the "
+                                           "10 M x 129 device factors are not copied to the host for a timing that does not depend on "
+                                           "the values")
         out["host_boundary"] = host_boundary(user_rows, k, bias, gamma, n_items)
         del users_f
     del eng, indptr, indices, counts, values, shard
     torch.cuda.empty_cache()
     return out
+
+
+def float64_path(cfg_name, dev, lib, iters=2):
+    """The reference's DEFAULT call -- train(cores = 4) on a SciPy (float64) count matrix -- keeps float64 factors through its
+    Pool variants (RecModel/wmf_model.py:146-157, :242-309); here that is wmf_half_step_f64.  One ALS iteration of it on the
+    same synthetic matrix as ``cfg_name``, timed after one warm-up iteration: ms per iteration, next to the float32 path's."""
+    from recmodel_amd import WMF
+    from recmodel_amd.engine import HipKernels
+    n_users, n_items, dbar, k, bias = synth.CONFIGS[cfg_name]
+    K = HipKernels()
+    ip, idx, val = synth.make_counts(n_users, n_items, dbar, SEEDS[cfg_name], device=dev)
+    w = val.double()
+    K.confidence_transform(w, 10.0, 1.0, 0)
+    f = k + 1 if bias else k
+    users_of = torch.repeat_interleave(torch.arange(n_users, device=dev), ip[1:] - ip[:-1])
+    order = torch.argsort(idx * n_users + users_of, stable=True)           # the transpose (wmf_model.py:128), entries by (item, user)
+    t_ip = torch.zeros(n_items + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.bincount(idx, minlength=n_items), 0, out=t_ip[1:])
+    csr = {"users": (ip, idx.to(torch.int32), w, n_users),
+           "items": (t_ip, users_of[order].to(torch.int32).contiguous(), w[order].contiguous(), n_items)}
+    del order, users_of
+    X = {"items": torch.from_numpy(np.ascontiguousarray(WMF(num_items=n_items, num_users=1, dim=k, gamma=0.1, weighted=True,
+                                                            bias=bias).items, dtype=np.float64)).to(dev), "users": None}
+    n_max = max(n_users, n_items)
+    ws = torch.empty(K.half_step_f64_workspace_bytes(f, n_max, n_max), dtype=torch.uint8, device=dev)
+    fail = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def half(side, fixed):
+        indptr, indices, vals, n = csr[side]
+        out = torch.empty(n, f, dtype=torch.float64, device=dev)
+        K.half_step_f64(X[fixed], X[fixed].shape[0], f, bias, indptr, indices, vals, n, 0.1, out, ws, fail)
+        X[side] = out
+
+    times = []
+    for it in range(iters + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        half("users", "items")
+        half("items", "users")
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    assert int(fail[0]) == 0
+    ms = min(times[1:])
+    return {"workload": f"{cfg_name}: k={k}{'+bias' if bias else ''}, {n_users}x{n_items}, {int(idx.numel())} nnz, float64 counts and factors",
+            "ms_per_iteration": ms, "row_updates_per_s": (n_users + n_items) / ms * 1e3, "first_iteration_ms": times[0],
+            "what": "wmf_half_step_f64 (users + items): the reference's cores > 1 variants, float64 end to end"}
 
 
 def main():
@@ -397,15 +461,35 @@ def main():
     scaling = args.scaling if args.scaling != "auto" else "strong"     # (one GPU: the first point of the same series)
     main_res = run_workload(args.config, args, world, rank, dev, lib, scaling,
                             with_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
-    also_name = args.also
-    if also_name == "auto":
-        also_name = {"cfg3": "cfg2" if world == 1 else "cfg4"}.get(args.config, "none")
+    # further workloads of the same run, under "also": names of synth.CONFIGS, optionally "name:zipf=A", comma separated.
+    # auto on one GPU: cfg2 (configs[1], with its CPU baseline), then the skewed variant of the main workload and cfg5's
+    # one-GPU slice with and without the power law (the README's other rows, driver-timed); on several GPUs the bias-free cfg4
+    also_arg = args.also
+    if also_arg == "auto":
+        also_arg = {"cfg3": "cfg2,cfg3:zipf=1.1,cfg5s,cfg5s:zipf=1.1" if world == 1 else "cfg4"}.get(args.config, "none")
+        if args.zipf:
+            also_arg = "none"
     also = None
-    if also_name != "none" and also_name in synth.CONFIGS:
-        r2 = run_workload(also_name, args, world, rank, dev, lib, scaling,
-                          with_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
-        also = {also_name: {"metric": "ALS user+item row-updates/sec", "unit": "row-updates/s", **r2}}
+    for n_also, item in enumerate([x for x in also_arg.split(",") if x and x != "none"]):
+        name, _, opt = item.partition(":")
+        if name not in synth.CONFIGS:
+            continue
+        z = float(opt.split("=")[1]) if opt.startswith("zipf=") else 0.0
+        r2 = run_workload(name, args, world, rank, dev, lib, scaling,
+                          with_cpu=(n_also == 0 and rank == 0 and world == 1 and not args.no_cpu_baseline), zipf=z)
+        also = also or {}
+        also[item.replace(":zipf=", "_zipf")] = {"metric": "ALS user+item row-updates/sec", "unit": "row-updates/s", **r2}
 
+    f64_block = None
+    if rank == 0 and world == 1 and args.config == "cfg3" and args.also == "auto" and not args.zipf:
+        try:
+            f64_block = float64_path("cfg2", dev, lib)
+            if also and "cfg2" in also:
+                f64_block["vs_float32_path"] = f64_block["ms_per_iteration"] / also["cfg2"]["ms_per_step"]
+        except Exception as exc:                      # reported, never silently dropped
+            f64_block = {"error": repr(exc)}
+    if also is not None and f64_block is not None:
+        also["float64_path"] = f64_block
     out = {
         "metric": "ALS user+item row-updates/sec", "value": main_res.pop("value"),
         "unit": "row-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

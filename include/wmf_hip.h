@@ -202,9 +202,11 @@ int wmf_confidence_transform_f64(double* values, int64_t nnz, double alpha, doub
  *   x_u = solve(Y~^T Y~ + lambda I + Y~_u^T diag(w) Y~_u,  Y~_u^T (w + 1))        in float64,
  * Y~ = Y with column 0 read as 1 and w = c_u - Y[idx, 0] for bias != 0 (:253-257, :279), rows without stored entries
  * are zero (:274-276, :296-298), and the float64 rows are stacked without a cast (np.stack, :246 / :261) -- so the
- * reference's `cores > 1` training continues on float64 factors.  This entry point is that arithmetic on the device,
- * without the whitening of the float32 path: Gramian in float64, then per row LU with partial pivoting (np.linalg.solve
- * is LAPACK gesv) carried in float64 -- the path for fidelity to those variants, one workgroup per row, not for speed.
+ * reference's `cores > 1` training continues on float64 factors (cores = 4 is the reference's default, :49-51).  This entry
+ * point is that arithmetic on the device, without the whitening of the float32 path: Gramian in float64, then per row
+ * the system accumulated and factored in registers, one workgroup per row (blocked Cholesky; a system that is not positive
+ * definite -- bias-adjusted weights below zero -- or not finite is redone by LU with partial pivoting, np.linalg.solve's
+ * gesv); both agree with the float64 oracle to 1e-10.
  *   Y [m, f] float64 row-major (dense, no padding), values float64[nnz], X [n, f] float64 out, all on the device;
  *   workspace: wmf_half_step_f64_workspace_bytes(f, m, n) bytes; fail_count (device int32, caller zeroes): += 1 per
  *   exactly singular row system (its X row is NaN; the reference raises LinAlgError).  Enqueues only. */

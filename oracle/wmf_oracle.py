@@ -240,7 +240,9 @@ def train(num_items, num_users, dim, gamma, utility_mat, iterations, eval_mat, c
     C.data = confidence_transform(C.data, alpha, beta, pre_process_count)
     CT = C.T.tocsr()
     step = recompute_factors_bias if bias else recompute_factors
-    out_dtype = "float64" if cores > 1 and C.dtype == np.float64 else None
+    # the Pool variants stack np.linalg.solve results of Y_rel (model dtype) x C.data products: float64 for float64 AND for
+    # integer weights (int64 from 'linear' on integer counts promotes the products, :285-287)
+    out_dtype = "float64" if cores > 1 and np.result_type(np.dtype(dtype), C.dtype) == np.float64 else None
     for it in range(iterations):
         users_f = step(items_f, C, gamma, dtype, out_dtype)
         items_f = step(users_f, CT, gamma, dtype, out_dtype)

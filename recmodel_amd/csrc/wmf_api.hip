@@ -260,7 +260,10 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, int bias, wmf_plan*
     // weights of a biased model, the matrix slices of the pivoted fallback for f > 144
     const int64_t nnz_all = p->nnz[0] + p->nnz[1] + p->nnz[2] + p->nnz[3];
     p->bias = bias != 0;
-    if (e == hipSuccess && bias && nnz_all > 0) e = hipMalloc((void**)&p->w_eff, (size_t)nnz_all * sizeof(float));
+    // (not at the split-layout widths -- k = 16 m with biases, the headline k = 128 among them: there the row kernels take the
+    // bias with the gathered row and never touch w_eff; 400 MB per side at cfg3.  The layout decision is latched here.)
+    p->split = bias && wmf_split_layout(f, wmf_ld_for(f));
+    if (e == hipSuccess && bias && !p->split && nnz_all > 0) e = hipMalloc((void**)&p->w_eff, (size_t)nnz_all * sizeof(float));
     if (e == hipSuccess && f > 144) e = hipMalloc((void**)&p->wide_ws, wmf_wide_lu_workspace_bytes(f));
     if (e == hipSuccess && p->heavy_count > 0) {
         const int64_t nfb = (f + 15) / 16, nt = nfb * (nfb + 1) / 2 + nfb;
@@ -316,6 +319,7 @@ int wmf_solve_rows(const wmf_plan* plan, const float* V, const float* bias_fixed
     if (n == 0) return WMF_OK;
     const int lrc = wmf_launch_solve(plan, V, bias_fixed, indptr, indices, values, f, ld, g, fail_count, (hipStream_t)stream);
     if (lrc == -2) { wmf_set_error("wmf_solve_rows: hipMemsetAsync failed"); return WMF_EHIP; }
+    if (lrc == -3) { wmf_set_error("wmf_solve_rows: the plan was created for the split layout of the whitened factors, the call is not (wmf_debug_set_flags(256) changed in between?)"); return WMF_EINVAL; }
     if (lrc) { wmf_set_error("wmf_solve_rows: no kernel for f=%d, ld=%d", f, ld); return WMF_EINVAL; }
     return check_launch("wmf_solve_rows");
 }

@@ -206,77 +206,105 @@ __device__ __forceinline__ float wmf_qsum(float v) {
 }
 
 // In-place Gauss-Jordan inverse of a symmetric positive definite 16 x 16 tile held row-distributed:
-// lane (r, q) has A[r][4q + reg] in a[reg].  Step K: column K becomes e_K first, then every row gets
-// row_i += nf_i * row_K with nf = -A[i][K]/piv (rows i != K) or 1/piv - 1 (row K).
+// lane (r, q) has A[r][4q + reg] in a[reg].  Step K: column K becomes e_K first, then every row i != K gets
+// row_i += nf_i * row_K with nf_i = -A[i][K] / piv.  The pivot row itself is NOT normalised inside the sweep: rows that have
+// been pivots stay at piv_K times their final value (the updates of the later steps are linear in the row, so the factor
+// rides along), every lane remembers 1 / piv of its own row in `dsc`, and the caller's sweep multiplies once at the end,
+// X = diag(dsc) . tile.  The obvious in-place form, row_K += (1 / piv - 1) row_K, rounds its multiplier at 2^-24 of ONE, not
+// of 1 / piv: a relative error of 6e-8 piv in the whole row, i.e. wrong inverses for confidence weights far above the
+// benchmark's (pre_process_count = 'linear' on large counts, RecModel/wmf_model.py:122-123; tests: test_weight_range_...).
 // The multiplier A[r][K] sits in lane (r, K / 4); LDS = true fetches it with one ds_bpermute (one LDS instruction,
 // long latency), false with two VALU lane swaps (five VALU instructions, no LDS round trip).
 // CHECK = false skips the pivot test: for callers whose tile is positive definite by construction (pivots >= 1)
-// and who test the result for NaN / Inf anyway.
-template <int K, bool LDS, bool CHECK>
-__device__ __forceinline__ void gj_inv_step(f32x4& a, const int (&baddr)[4], int r, int q, bool& ok) {
+// and who test the result for NaN / Inf anyway.  CAP: a pivot above WMF_PIVOT_CAP also clears `ok` -- for the block
+// eliminations that multiply by the explicit inverse of the pivot tile: that is as accurate as a triangular solve only while
+// the tile is well conditioned (errors grow with cond(tile)^2, and the split-f16 parts of 1 / piv lose bits to the f16
+// subnormal range as piv grows).  Whitened systems under the usual confidence weights have pivots in [1, 1 + max w] -- 20 for
+// alpha = 10, 'log', counts up to 6 -- so the cap never fires there; a row that carries weights of 1e3 and more (alpha * count,
+// 'linear') goes to the pivoted LU kernel instead, which is slower and as accurate as float32 allows (measured on MI355X,
+// tests/scale/diag_weights_mixed.py: 1e-3 at cond 1e4 where the tile-inverse path gave 0.1 .. 0.5).
+#define WMF_PIVOT_CAP 32.f
+template <int K, bool LDS, bool CHECK, bool CAP = false>
+__device__ __forceinline__ void gj_inv_step(f32x4& a, float& dsc, const int (&baddr)[4], int r, int q, bool& ok) {
     constexpr int kq = K >> 2, kr = K & 3;
     const float akr = a[kr];     // copy first: __builtin_bit_cast applied to the vector-element lvalue itself reads element 0
     const float piv = rlw(akr, K + 16 * kq);
     if constexpr (CHECK) { if (!(piv > 1e-20f)) ok = false; }
+    if constexpr (CAP) { if (piv > WMF_PIVOT_CAP) ok = false; }
     const float inv = __builtin_amdgcn_rcpf(piv);
     float fk;
     if constexpr (LDS) fk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(baddr[kq], __builtin_bit_cast(int, akr)));
     else               fk = wmf_bcast_rowgroup<kq>(akr);
     if (q == kq) a[kr] = (r == K) ? 1.f : 0.f;
-    const float nf = (r == K) ? inv - 1.f : -fk * inv;
+    const float nf = (r == K) ? 0.f : -fk * inv;
+    dsc = (r == K) ? inv : dsc;
     float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
     fmac_bcast4_self<K>(a0, a1, a2, a3, nf);
     a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3;
 }
-template <bool LDS = true, bool CHECK = true, int... Ks>
+template <bool LDS = true, bool CHECK = true, bool CAP = false, int... Ks>
 __device__ __forceinline__ void gj_inv_sweep(f32x4& a, const int (&baddr)[4], int r, int q, bool& ok,
                                              std::integer_sequence<int, Ks...>) {
-    (gj_inv_step<Ks, LDS, CHECK>(a, baddr, r, q, ok), ...);
+    float dsc = 1.f;
+    (gj_inv_step<Ks, LDS, CHECK, CAP>(a, dsc, baddr, r, q, ok), ...);
+    a *= dsc;
 }
 
 // The same step for a wave that runs alone on its SIMD (the heavy-row kernels): every instruction costs issue time there,
 // so the lane masks are compile-time constants in scalar registers instead of compares (r == K: lanes K, K + 16, ..;
-// q == K / 4: one 16-lane group), and the multiplier is formed as  nf = (e_K - f) / piv,  e_K = [r == K]  -- which is
-// 1 / piv - 1 in the pivot row (f = piv there) and -f / piv elsewhere, the e_K doubling as the preset of column K.
-// 14 VALU instructions a step where the step above compiles to 19.  No pivot test: the caller checks the result.
+// q == K / 4: one 16-lane group), and the multiplier is formed as  nf = (e_K f - f) / piv,  e_K = [r == K]  -- which is
+// 0 in the pivot row (un-normalised sweep, as above) and -f / piv elsewhere, the e_K doubling as the preset of column K.
+// 15 VALU instructions a step where the step above compiles to 20.  No pivot test: the caller checks the result.
 // BP: the multiplier column by ONE ds_bpermute_b32 (r4 = 4 (lane & 15), the row group in the instruction's offset field, the
 // wait in the same asm block so that hipcc sees neither) instead of five VALU instructions -- for callers that run two
 // waves per SIMD, where the permute's latency is the other wave's issue time.
 template <int K, bool BP = false>
-__device__ __forceinline__ void gj_inv_step_lean(f32x4& a, int& pmin, int r4 = 0) {
+__device__ __forceinline__ void gj_inv_step_lean(f32x4& a, float& dsc, int& pmin, int& pmax, int r4 = 0) {
     constexpr int kq = K >> 2, kr = K & 3;
     const float akr = a[kr];
     const float piv = rlw(akr, K + 16 * kq);
-    // pivot test on the scalar unit: the smallest pivot BIT PATTERN as a signed integer -- for positive floats the integer
-    // order is the float order, a negative pivot is a negative integer -- which the caller compares with that of 1e-20f
-    // (WMF_PIVOT_MIN_BITS) once.  A NaN passes, and reaches the solution, which the caller tests.
+    // pivot tests on the scalar unit: the smallest and the largest pivot BIT PATTERN as signed integers -- for positive floats
+    // the integer order is the float order, a negative pivot is a negative integer -- which the caller compares with those of
+    // 1e-20f (WMF_PIVOT_MIN_BITS) and of WMF_PIVOT_CAP once.  A NaN passes, and reaches the solution, which the caller tests.
     pmin = min(pmin, __builtin_bit_cast(int, piv));
+    pmax = max(pmax, __builtin_bit_cast(int, piv));
     const float inv = __builtin_amdgcn_rcpf(piv);
     float fk;
     if constexpr (BP) asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)" : "=v"(fk) : "v"(r4), "v"(akr), "n"(64 * kq));
     else fk = wmf_bcast_rowgroup<kq>(akr);
     // (the masks are shifted into place next to their use: as C++ constants hipcc computes all twenty once, ahead of the
     // eight sweeps of a row, and then spills them to VGPR lanes -- v_writelane / v_readlane around every use)
+    // eK = [r == K]; dsc = 1 / piv on the lanes of row K (the un-normalised sweep, see gj_inv_step); pre = column K preset
     float eK, pre;
     unsigned long long tmp;
-    asm volatile("s_lshl_b64 %2, %4, %5\n\t"
+    asm volatile("s_lshl_b64 %2, %5, %6\n\t"
                  "v_cndmask_b32 %0, 0, 1.0, %2\n\t"
-                 "s_lshl_b64 %2, 0xffff, %6\n\t"
-                 "v_cndmask_b32 %1, %3, %0, %2"
-                 : "=&v"(eK), "=v"(pre), "=&s"(tmp)
-                 : "v"(akr), "s"(0x0001000100010001ull), "n"(K), "n"(16 * kq)
+#ifndef WMF_GJ_NORMALISED
+                 "v_cndmask_b32 %3, %3, %8, %2\n\t"
+#endif
+                 "s_lshl_b64 %2, 0xffff, %7\n\t"
+                 "v_cndmask_b32 %1, %4, %0, %2"
+                 : "=&v"(eK), "=v"(pre), "=&s"(tmp), "+v"(dsc)
+                 : "v"(akr), "s"(0x0001000100010001ull), "n"(K), "n"(16 * kq), "v"(inv)
                  : "scc");                                           // s_lshl_b64 writes SCC
     a[kr] = pre;
+#ifdef WMF_GJ_NORMALISED                                             // lab only (tools/build_variant.sh): the round-2 step, for A/B timing
     const float nf = (eK - fk) * inv;
+#else
+    const float nf = __builtin_fmaf(eK, fk, -fk) * inv;              // 0 in the pivot row, -f / piv elsewhere
+#endif
     float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
     fmac_bcast4_self<K>(a0, a1, a2, a3, nf);
     a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3;
 }
+// (the caller multiplies the swept tile by dsc: X = diag(dsc) . a)
 template <bool BP = false, int... Ks>
-__device__ __forceinline__ void gj_inv_sweep_lean(f32x4& a, int& pmin, int r4, std::integer_sequence<int, Ks...>) {
-    (gj_inv_step_lean<Ks, BP>(a, pmin, r4), ...);
+__device__ __forceinline__ void gj_inv_sweep_lean(f32x4& a, float& dsc, int& pmin, int& pmax, int r4, std::integer_sequence<int, Ks...>) {
+    dsc = 1.f;
+    (gj_inv_step_lean<Ks, BP>(a, dsc, pmin, pmax, r4), ...);
 }
 #define WMF_PIVOT_MIN_BITS 0x1e3ce508
+#define WMF_PIVOT_CAP_BITS 0x42000000          /* 32.f = WMF_PIVOT_CAP */
 
 // The same inverse as a SYMMETRIC sweep whose rank-one update is one f32 MFMA -- for callers that run two waves per SIMD and
 // are bound by VALU issue, with MFMA time to spare.  The tile stays symmetric, so the row-distributed layout above is also

@@ -1,49 +1,346 @@
 // One half step in float64 (gfx950): the arithmetic of the reference's Pool variants, RecModel/wmf_model.py:242-309
-// (recompute_factors_par / recompute_factors_bias_par and their *_intern row functions).  With a float64 count matrix those
-// keep every row result in float64 -- np.stack of the per-row np.linalg.solve outputs, no cast back to the model dtype --
-// so from the second half step on the reference's cores > 1 training runs on float64 factors, float64 Gramians and float64
-// row systems.  This file is that pipeline, stated directly and without the whitening of the float32 path:
-//   gram64_kernel + gram64_reduce_kernel   G = Y~^T Y~ + lambda I          (:244 / :258; Y~ = Y with column 0 read as 1, :257)
-//   solve64_kernel                         per row u: A = G + Y_u^T diag(w) Y_u,  b = Y_u^T (w + 1)   (:285-287 / :305-309),
-//                                          w = c_u - bias[idx] for bias models (:279); x = solve(A, b) by LU with partial
-//                                          pivoting (np.linalg.solve is LAPACK gesv: the same algorithm, so rows whose
-//                                          bias-adjusted weights make A indefinite are solved like the reference solves
-//                                          them); rows without stored entries are zero (:274-276 / :296-298)
-// It is the correctness path for `cores > 1`, not a fast path: one workgroup per row, the row system in an L2-resident
-// workspace slice, f^3 / 3 float64 FMAs per row on the vector units (the reference's own Pool path is ~10x slower than its
-// serial loop).
+// (recompute_factors_par / recompute_factors_bias_par and their *_intern row functions).  With a float64 (or integer) count
+// matrix those keep every row result in float64 -- np.stack of the per-row np.linalg.solve outputs, no cast back to the model
+// dtype -- so from the second half step on the reference's cores > 1 training runs on float64 factors, float64 Gramians and
+// float64 row systems.  cores = 4 is the reference's DEFAULT (wmf_model.py:49-51) and SciPy matrices default to float64, so
+// this is the path a drop-in caller lands on.  Round 3: register-blocked kernels instead of one read-modify-write of the
+// system per stored entry.
+//   gram64v2_kernel + gram64v2_reduce_kernel   G = Y~^T Y~ + lambda I      (:244 / :258; Y~ = Y with column 0 read as 1, :257)
+//       a workgroup stages 16 rows of Y at a time in LDS (coalesced) and every thread keeps 4 x 4 blocks of the upper
+//       triangle in registers (8 LDS reads of 16 bytes per 16 FMAs); block partial sums are added in a fixed order.
+//   solve64v2_kernel<NB>   per row u: A = G + Y_u^T diag(w) Y_u,  b = Y_u^T (w + 1)   (:285-287 / :305-309), w = c_u - bias[idx]
+//       for bias models (:279).  One 256-thread workgroup per row; the AUGMENTED upper triangle [A | b] lives in registers
+//       as 4 x 4 blocks (NB per thread: 1 up to f = 84, 3 up to 148, 9 up to 260) from the first gathered entry to the
+//       solution: entries are gathered 16 at a time into LDS and accumulated like the Gramian, then a right-looking blocked
+//       Cholesky A = R^T R runs on the same registers -- per block column: the diagonal block's owner factors and inverts its
+//       4 x 4 block, the owners of that block row form their R blocks (and publish them in a double-buffered LDS panel), the
+//       rest subtract their rank-4 update -- with b riding along as one more block column (so R^-T b is there when the
+//       factorisation ends), and the back substitution R x = y walks the block columns again with each R block still in the
+//       registers of its owner.  Two barriers per block column and phase, no workspace.
+//       np.linalg.solve is LU with partial pivoting; for a positive definite system Cholesky gives the same solution to a
+//       few ulp of float64 (the tests hold both to 1e-10 of the oracle).
+//   solve64_lu_kernel      rows whose system is NOT positive definite (bias-adjusted weights below zero, :279) or not finite:
+//       the factorisation above meets a non-positive pivot and hands the row over -- LU with partial pivoting (first maximum as
+//       idamax, i.e. gesv), the right-hand side carried along, the row system in an L2-resident workspace slice; an exactly
+//       singular system is counted and NaN-filled (the reference raises).  Rows without stored entries are zero (:274-276 /
+//       :296-298).
 #include "../../include/wmf_hip.h"
 #include "wmf_internal.h"
 
-__global__ __launch_bounds__(256) void gram64_kernel(const double* __restrict__ Y, int64_t m, int f, int bias,
-                                                     double* __restrict__ partial, int64_t rows_per_block) {
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(m, r0 + rows_per_block);
-    for (int el = threadIdx.x; el < f * f; el += 256) {
-        const int i = el / f, j = el % f;
-        double acc = 0.0;
-        for (int64_t r = r0; r < r1; ++r) {
-            const double yi = (bias && i == 0) ? 1.0 : Y[r * f + i];
-            const double yj = (bias && j == 0) ? 1.0 : Y[r * f + j];
-            acc += yi * yj;
+// ---- 4 x 4 blocks of the (augmented) upper triangle, dealt to the 256 threads of a workgroup -------------------------------
+// f4 = ceil(f / 4) block rows; row bi holds the blocks (bi, bi) .. (bi, f4 - 1) and, when RHS, one more at column f4: the
+// right-hand side (its first column; the other three stay zero).  Block number b = n * 256 + thread, n < NB.
+#define F64_R 16                                   /* gathered entries (or rows of Y) staged per pass */
+__device__ __forceinline__ void f64_decode(int b, int f4, bool rhs, int& bi, int& bj) {
+    int r = 0, rem = b;
+    const int extra = rhs ? 1 : 0;
+    while (r < f4 && rem >= f4 - r + extra) { rem -= f4 - r + extra; ++r; }
+    bi = r; bj = r + rem;
+}
+static int f64_blocks(int f, bool rhs) { const int f4 = (f + 3) / 4; return f4 * (f4 + 1) / 2 + (rhs ? f4 : 0); }
+static int f64_nb(int nblk) { return nblk <= 256 ? 1 : nblk <= 512 ? 2 : nblk <= 768 ? 3 : nblk <= 1280 ? 5 : 9; }
+
+// acc[n] += sum_e (w_e a_e) b_e^T over the staged entries: a_e = ys[e][4 bi ..], b_e = ys[e][4 bj ..]; the right-hand-side
+// block (bj == f4) takes b_e = (p_e, 0, 0, 0) un-weighted (column FP of the staged row holds p_e)
+template <int NB>
+__device__ __forceinline__ void f64_accumulate(double (&acc)[NB][16], const int (&bi)[NB], const int (&bj)[NB], const bool (&on)[NB],
+                                               const double* __restrict__ ys, int ldy, const double* __restrict__ wv, int nvalid, int f4) {
+    for (int e = 0; e < nvalid; ++e) {
+        const double w = wv[e];
+        const double* row = ys + e * ldy;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            if (!on[n]) continue;
+            const double2 a01 = *reinterpret_cast<const double2*>(row + 4 * bi[n]), a23 = *reinterpret_cast<const double2*>(row + 4 * bi[n] + 2);
+            const double2 b01 = *reinterpret_cast<const double2*>(row + 4 * bj[n]), b23 = *reinterpret_cast<const double2*>(row + 4 * bj[n] + 2);
+            const double ws = bj[n] == f4 ? 1.0 : w;
+            const double a[4] = {a01.x * ws, a01.y * ws, a23.x * ws, a23.y * ws};
+            const double b[4] = {b01.x, b01.y, b23.x, b23.y};
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[n][4 * x + y] = __builtin_fma(a[x], b[y], acc[n][4 * x + y]);
         }
-        partial[(int64_t)blockIdx.x * f * f + el] = acc;
     }
 }
 
-__global__ __launch_bounds__(256) void gram64_reduce_kernel(const double* __restrict__ partial, int nblocks, int f, double lambda,
-                                                            double* __restrict__ G) {
-    const int el = blockIdx.x * 256 + threadIdx.x;
-    if (el >= f * f) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * f * f + el];       // fixed order: reproducible
-    G[el] = s + ((el / f == el % f) ? lambda : 0.0);
+// ---- Gramian: partial[wg][block][16] = upper-triangle blocks of Y~^T Y~ over this workgroup's rows -----------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void gram64v2_kernel(const double* __restrict__ Y, int64_t m, int f, int bias,
+                                                       double* __restrict__ partial, int64_t rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) double sm64[];
+    const int t = threadIdx.x;
+    const int f4 = (f + 3) >> 2, FP = 4 * f4, nblk = f4 * (f4 + 1) / 2;
+    double* ys = sm64;                              // [F64_R][FP]
+    double* wv = ys + F64_R * FP;                   // [F64_R] ones
+    int bi[NB], bj[NB];
+    bool on[NB];
+    double acc[NB][16];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int b = n * 256 + t;
+        on[n] = b < nblk;
+        f64_decode(on[n] ? b : 0, f4, false, bi[n], bj[n]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[n][i] = 0.0;
+    }
+    if (t < F64_R) wv[t] = 1.0;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(m, r0 + rows_per_block);
+    for (int64_t c0 = r0; c0 < r1; c0 += F64_R) {
+        const int nvalid = (int)min((int64_t)F64_R, r1 - c0);
+        __syncthreads();                            // the previous pass is done with ys
+        for (int i = t; i < nvalid * FP; i += 256) {
+            const int e = i / FP, c = i - e * FP;
+            ys[i] = c < f ? ((bias && c == 0) ? 1.0 : Y[(c0 + e) * f + c]) : 0.0;
+        }
+        __syncthreads();
+        f64_accumulate<NB>(acc, bi, bj, on, ys, FP, wv, nvalid, f4 + 1);       // (f4 + 1: no right-hand-side block here)
+    }
+    double* out = partial + (int64_t)blockIdx.x * nblk * 16;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        if (!on[n]) continue;
+        double2* o = reinterpret_cast<double2*>(out + (int64_t)(n * 256 + t) * 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = make_double2(acc[n][2 * i], acc[n][2 * i + 1]);
+    }
 }
 
-// one workgroup per row (grid-stride); A (f x f), b (f) in this workgroup's workspace slice
-__global__ __launch_bounds__(256) void solve64_kernel(const double* __restrict__ Y, int f, int bias, const double* __restrict__ G,
-                                                      const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
-                                                      const double* __restrict__ vals, int64_t n, double* __restrict__ X,
-                                                      double* __restrict__ ws, int32_t* __restrict__ fail) {
+// G = sum of the partial blocks (fixed order: reproducible) + lambda I, both triangles
+__global__ __launch_bounds__(256) void gram64v2_reduce_kernel(const double* __restrict__ partial, int nwg, int f, double lambda,
+                                                              double* __restrict__ G) {
+    const int f4 = (f + 3) >> 2, nblk = f4 * (f4 + 1) / 2;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= nblk * 16) return;
+    const int b = id >> 4, el = id & 15;
+    int bi, bj;
+    f64_decode(b, f4, false, bi, bj);
+    const int gi = 4 * bi + (el >> 2), gj = 4 * bj + (el & 3);
+    if (gi >= f || gj >= f || gj < gi) return;      // padding, or the mirrored half of a diagonal block
+    double s = 0.0;
+    for (int w = 0; w < nwg; ++w) s += partial[((int64_t)w * nblk + b) * 16 + el];
+    if (gi == gj) s += lambda;
+    G[(int64_t)gi * f + gj] = s;
+    G[(int64_t)gj * f + gi] = s;
+}
+
+// ---- one row system per workgroup, in registers from the first gathered entry to the solution --------------------------------
+// Dynamic LDS (doubles): ys [F64_R][FP + 4] | wv [F64_R] | pv [F64_R] | panel [2][(f4 + 1) * 16] | dbuf [2][16] | yv [FP] |
+// xs [4] | ib (int) [F64_R] + flag
+static size_t solve64v2_lds_bytes(int f) {
+    const int f4 = (f + 3) / 4, FP = 4 * f4;
+    return (size_t)(F64_R * (FP + 4) + 2 * F64_R + 2 * (f4 + 1) * 16 + 32 + FP + 4) * 8 + (F64_R + 4) * 4;
+}
+template <int NB>
+__global__ __launch_bounds__(256) void solve64v2_kernel(const double* __restrict__ Y, int f, int bias, const double* __restrict__ G,
+                                                        const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                        const double* __restrict__ vals, int64_t n, double* __restrict__ X,
+                                                        int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count) {
+    extern __shared__ __attribute__((aligned(16))) double sm64[];
+    const int t = threadIdx.x;
+    const int f4 = (f + 3) >> 2, FP = 4 * f4, FPA = FP + 4, nblk = f4 * (f4 + 1) / 2 + f4;
+    double* ys = sm64;
+    double* wv = ys + F64_R * FPA;
+    double* pv = wv + F64_R;
+    double* panel = pv + F64_R;
+    double* dbuf = panel + 2 * (f4 + 1) * 16;
+    double* yv = dbuf + 32;
+    double* xs = yv + FP;
+    int* ib = reinterpret_cast<int*>(xs + 4);
+    int* flag = ib + F64_R;
+    int bi[NB], bj[NB];
+    bool on[NB];
+#pragma unroll
+    for (int n_ = 0; n_ < NB; ++n_) {
+        const int b = n_ * 256 + t;
+        on[n_] = b < nblk;
+        f64_decode(on[n_] ? b : 0, f4, true, bi[n_], bj[n_]);
+    }
+    for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+        const int64_t lo = indptr[row], hi = indptr[row + 1];
+        if (hi == lo) {                                              // no stored entries: zeros (wmf_model.py:274-276, :296-298)
+            for (int c = t; c < f; c += 256) X[row * f + c] = 0.0;
+            continue;
+        }
+        double acc[NB][16];
+#pragma unroll
+        for (int n_ = 0; n_ < NB; ++n_)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[n_][i] = 0.0;
+        if (t == 0) *flag = 0;
+        // ---- A = sum_e w_e y_e y_e^T, b = sum_e (w_e + 1) y_e over the row's entries, F64_R at a time
+        for (int64_t c0 = lo; c0 < hi; c0 += F64_R) {
+            const int nvalid = (int)min((int64_t)F64_R, hi - c0);
+            __syncthreads();                                         // the previous pass is done with ys / wv
+            if (t < nvalid) {
+                const int idx = indices[c0 + t];
+                const double w = vals[c0 + t] - (bias ? Y[(int64_t)idx * f] : 0.0);   // data - bias[idx], :279
+                ib[t] = idx; wv[t] = w; pv[t] = w + 1.0;
+            }
+            __syncthreads();
+            for (int i = t; i < nvalid * FPA; i += 256) {
+                const int e = i / FPA, c = i - e * FPA;
+                double v = 0.0;
+                if (c < f) v = (bias && c == 0) ? 1.0 : Y[(int64_t)ib[e] * f + c];
+                else if (c == FP) v = pv[e];
+                ys[i] = v;
+            }
+            __syncthreads();
+            f64_accumulate<NB>(acc, bi, bj, on, ys, FPA, wv, nvalid, f4);
+        }
+        // ---- + G (lambda included); rows / columns of padding get a unit diagonal: their unknowns are zero
+#pragma unroll
+        for (int n_ = 0; n_ < NB; ++n_) {
+            if (!on[n_] || bj[n_] == f4) continue;
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    const int gi = 4 * bi[n_] + x, gj = 4 * bj[n_] + y;
+                    if (gi < f && gj < f) acc[n_][4 * x + y] += G[(int64_t)gi * f + gj];
+                    else if (gi == gj) acc[n_][4 * x + y] += 1.0;
+                }
+        }
+        // ---- right-looking blocked Cholesky A = R^T R on the registers, b riding along as block column f4
+        bool bad = false;
+#pragma unroll 1
+        for (int kb = 0; kb < f4; ++kb) {
+            double* pan = panel + (kb & 1) * (f4 + 1) * 16;
+            double* db = dbuf + (kb & 1) * 16;
+#pragma unroll
+            for (int n_ = 0; n_ < NB; ++n_) {
+                if (on[n_] && bi[n_] == kb && bj[n_] == kb) {        // (a) the diagonal block: R_kk, then its inverse (upper triangular)
+                    double* a = acc[n_];
+                    double r[4][4], iv[4][4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double dgl = a[5 * i];
+#pragma unroll
+                        for (int k = 0; k < i; ++k) dgl -= r[k][i] * r[k][i];
+                        if (!(dgl > 0.0)) bad = true;                // not positive definite (or NaN): the LU kernel takes the row
+                        const double rii = sqrt(dgl), inv = 1.0 / rii;
+                        r[i][i] = rii;
+#pragma unroll
+                        for (int j = i + 1; j < 4; ++j) {
+                            double v = a[4 * i + j];
+#pragma unroll
+                            for (int k = 0; k < i; ++k) v -= r[k][i] * r[k][j];
+                            r[i][j] = v * inv;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) iv[i][j] = 0.0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        iv[j][j] = 1.0 / r[j][j];
+#pragma unroll
+                        for (int i = j - 1; i >= 0; --i) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int k = i + 1; k <= j; ++k) v += r[i][k] * iv[k][j];
+                            iv[i][j] = -v / r[i][i];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { a[i] = iv[i >> 2][i & 3]; db[i] = a[i]; }   // the owner keeps R_kk^-1 for the back substitution
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int n_ = 0; n_ < NB; ++n_) {
+                if (on[n_] && bi[n_] == kb && bj[n_] > kb) {         // (b) block row kb: R_kj = R_kk^-T A_kj
+                    double* a = acc[n_];
+                    double u[16];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int k = 0; k <= x; ++k) v += db[4 * k + x] * a[4 * k + y];
+                            u[4 * x + y] = v;
+                        }
+                    double2* o = reinterpret_cast<double2*>(pan + bj[n_] * 16);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = make_double2(u[2 * i], u[2 * i + 1]);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) a[i] = u[i];
+                    if (bj[n_] == f4) {                              // y_kb = (R^-T b)_kb: where the back substitution starts
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) yv[4 * kb + x] = u[4 * x];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int n_ = 0; n_ < NB; ++n_) {
+                if (on[n_] && bi[n_] > kb) {                         // (c) trailing update A_ij -= R_ki^T R_kj
+                    const double* ui = pan + bi[n_] * 16;
+                    const double* uj = pan + bj[n_] * 16;
+                    double* a = acc[n_];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const double2 i01 = *reinterpret_cast<const double2*>(ui + 4 * k), i23 = *reinterpret_cast<const double2*>(ui + 4 * k + 2);
+                        const double2 j01 = *reinterpret_cast<const double2*>(uj + 4 * k), j23 = *reinterpret_cast<const double2*>(uj + 4 * k + 2);
+                        const double iv_[4] = {i01.x, i01.y, i23.x, i23.y};
+                        const double jv_[4] = {j01.x, j01.y, j23.x, j23.y};
+#pragma unroll
+                        for (int x = 0; x < 4; ++x)
+#pragma unroll
+                            for (int y = 0; y < 4; ++y) a[4 * x + y] = __builtin_fma(-iv_[x], jv_[y], a[4 * x + y]);
+                    }
+                }
+            }
+        }
+        if (bad) *flag = 1;
+        __syncthreads();
+        if (*flag) {                                                 // uniform: hand the row to the pivoted kernel
+            if (t == 0) fb_rows[atomicAdd(fb_count, 1)] = (int32_t)row;
+            __syncthreads();
+            continue;
+        }
+        // ---- back substitution R x = y, block column by block column; every R block is still in its owner's registers
+#pragma unroll 1
+        for (int kb = f4 - 1; kb >= 0; --kb) {
+#pragma unroll
+            for (int n_ = 0; n_ < NB; ++n_) {
+                if (on[n_] && bi[n_] == kb && bj[n_] == kb) {
+                    const double* iv = acc[n_];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int j = i; j < 4; ++j) v += iv[4 * i + j] * yv[4 * kb + j];
+                        xs[i] = v;
+                        if (4 * kb + i < f) X[row * f + 4 * kb + i] = v;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int n_ = 0; n_ < NB; ++n_) {
+                if (on[n_] && bj[n_] == kb && bi[n_] < kb) {         // y_bi -= R_(bi, kb) x_kb: one owner per (bi, kb)
+                    const double* u = acc[n_];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        yv[4 * bi[n_] + x] -= u[4 * x] * xs[0] + u[4 * x + 1] * xs[1] + u[4 * x + 2] * xs[2] + u[4 * x + 3] * xs[3];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// LU with partial pivoting for the rows of `rows` (count on the device): one workgroup per row (grid-stride); A (f x f), b (f)
+// in this workgroup's workspace slice
+__global__ __launch_bounds__(256) void solve64_lu_kernel(const double* __restrict__ Y, int f, int bias, const double* __restrict__ G,
+                                                         const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                         const double* __restrict__ vals, const int32_t* __restrict__ rows,
+                                                         const int32_t* __restrict__ count_ptr, double* __restrict__ X,
+                                                         double* __restrict__ ws, int32_t* __restrict__ fail) {
     __shared__ double ys[WMF_MAX_F + 3];
     __shared__ double red_v[256];
     __shared__ int red_i[256];
@@ -51,7 +348,9 @@ __global__ __launch_bounds__(256) void solve64_kernel(const double* __restrict__
     const int t = threadIdx.x;
     double* A = ws + (size_t)blockIdx.x * ((size_t)f * f + f);
     double* b = A + (size_t)f * f;
-    for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+    const int64_t n = *count_ptr;
+    for (int64_t it = blockIdx.x; it < n; it += gridDim.x) {
+        const int64_t row = rows[it];
         const int64_t lo = indptr[row], hi = indptr[row + 1];
         if (hi == lo) {                                              // no stored entries: zeros (wmf_model.py:274-276, :296-298)
             for (int c = t; c < f; c += 256) X[row * f + c] = 0.0;
@@ -141,32 +440,63 @@ __global__ __launch_bounds__(256) void confidence64_kernel(double* __restrict__ 
 }
 
 static int gram64_blocks(int64_t m) {
-    int64_t nb = (m + 63) / 64;
+    int64_t nb = (m + 255) / 256;                   // at least 256 rows (16 passes) per workgroup
     if (nb > 512) nb = 512;
     return (int)(nb < 1 ? 1 : nb);
 }
-static int solve64_blocks(int64_t n) { return (int)(n < 1 ? 1 : (n > 2048 ? 2048 : n)); }
+static int solve64_blocks(int64_t n) { return (int)(n < 1 ? 1 : (n > 4096 ? 4096 : n)); }
+#define WMF_F64_LU_GRID 256
 
-// workspace: [gram partials nb x f x f][G f x f][solve slices nblocks x (f x f + f)] doubles
+// workspace: [gram partials nwg x blocks x 16][G f x f][LU slices WMF_F64_LU_GRID x (f x f + f)] doubles [fallback rows n + 64 int32]
 int64_t wmf_f64_ws_bytes(int f, int64_t m, int64_t n) {
     const int64_t ff = (int64_t)f * f;
-    return 8 * ((int64_t)gram64_blocks(m) * ff + ff + (int64_t)solve64_blocks(n) * (ff + f)) + 256;
+    return 8 * ((int64_t)gram64_blocks(m) * f64_blocks(f, false) * 16 + ff + (int64_t)WMF_F64_LU_GRID * (ff + f)) + 4 * (n + 64) + 256;
+}
+
+template <int NB>
+static void launch_f64_nb(const double* Y, int64_t m, int f, int bias, const int64_t* indptr, const int32_t* indices,
+                          const double* values, int64_t n, double lambda, double* X, double* partial, double* G, int32_t* fb_rows,
+                          int32_t* fb_count, int nwg, hipStream_t st) {
+    const int f4 = (f + 3) / 4, FP = 4 * f4;
+    const size_t lds_g = (size_t)(F64_R * FP + F64_R) * 8, lds_s = solve64v2_lds_bytes(f);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gram64v2_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)solve64v2_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    static const char* nmg = wmf_kname("gram64v2_kernel<%d>", NB);
+    static const char* nms = wmf_kname("solve64v2_kernel<%d>", NB);
+    const int64_t rpb = (m + nwg - 1) / nwg;
+    WMF_LAUNCH(nmg, (gram64v2_kernel<NB>), dim3(nwg), dim3(256), lds_g, st, Y, m, f, bias, partial, rpb);
+    const int nel = f64_blocks(f, false) * 16;
+    WMF_LAUNCH("gram64v2_reduce_kernel", gram64v2_reduce_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, partial, nwg, f,
+               lambda, G);
+    if (n > 0)
+        WMF_LAUNCH(nms, (solve64v2_kernel<NB>), dim3(solve64_blocks(n)), dim3(256), lds_s, st, Y, f, bias, G, indptr, indices, values,
+                   n, X, fb_rows, fb_count);
 }
 
 int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const int64_t* indptr, const int32_t* indices,
                              const double* values, int64_t n, double lambda, double* X, void* ws, int32_t* fail, hipStream_t st) {
     const int64_t ff = (int64_t)f * f;
-    const int nb = gram64_blocks(m);
+    const int nwg = gram64_blocks(m);
     double* partial = static_cast<double*>(ws);
-    double* G = partial + (int64_t)nb * ff;
+    double* G = partial + (int64_t)nwg * f64_blocks(f, false) * 16;
     double* slices = G + ff;
-    const int64_t rpb = (m + nb - 1) / nb;
-    WMF_LAUNCH("gram64_kernel", gram64_kernel, dim3(nb), dim3(256), 0, st, Y, m, f, bias, partial, rpb);
-    WMF_LAUNCH("gram64_reduce_kernel", gram64_reduce_kernel, dim3((unsigned)((ff + 255) / 256)), dim3(256), 0, st, partial, nb, f,
-               lambda, G);
-    if (n > 0)
-        WMF_LAUNCH("solve64_kernel", solve64_kernel, dim3(solve64_blocks(n)), dim3(256), 0, st, Y, f, bias, G, indptr, indices,
-                   values, n, X, slices, fail);
+    int32_t* fb_count = reinterpret_cast<int32_t*>(slices + (int64_t)WMF_F64_LU_GRID * (ff + f));
+    int32_t* fb_rows = fb_count + 64;
+    if (hipMemsetAsync(fb_count, 0, 256, st) != hipSuccess) return -2;
+    // (the Gramian has no right-hand-side column, the row systems do: the block count per thread follows the larger)
+    switch (f64_nb(f64_blocks(f, true))) {
+#define C_(N) case N: launch_f64_nb<N>(Y, m, f, bias, indptr, indices, values, n, lambda, X, partial, G, fb_rows, fb_count, nwg, st); break;
+        C_(1) C_(2) C_(3) C_(5) C_(9)
+#undef C_
+        default: return -1;
+    }
+    if (n > 0)                                      // rows the Cholesky kernel could not take (count on the device; none as a rule)
+        WMF_LAUNCH("solve64_lu_kernel", solve64_lu_kernel, dim3(WMF_F64_LU_GRID), dim3(256), 0, st, Y, f, bias, G, indptr, indices,
+                   values, fb_rows, fb_count, X, slices, fail);
     return 0;
 }
 

@@ -19,7 +19,8 @@ struct wmf_plan {
     int f;
     int64_t count[WMF_NBINS];  // rows per bin
     int64_t count8, nnz8;      // rows of the first bin with at most 8 entries (and their entries); they come first in rows[WMF_BIN_LOW16]
-    bool bias;                 // created for a biased model: w_eff is allocated
+    bool bias;                 // created for a biased model: w_eff is allocated (unless split)
+    bool split;                // latched at creation: the whitened fixed side comes in the split layout (no w_eff needed)
     int64_t nnz[WMF_NBINS];    // stored entries per bin
     int32_t* rows[WMF_NBINS];  // device: row ids of each bin (slices of rows_all)
     int32_t* rows_all;         // device: n row ids grouped by bin

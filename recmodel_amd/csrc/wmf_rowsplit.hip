@@ -421,7 +421,7 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
             constexpr int b0 = rs_base<NFB, W>(S);
             if constexpr (bi < NFB) {
                 f32x4 X = acc[b0];
-                gj_inv_sweep(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
+                gj_inv_sweep<true, true, true>(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});   // (pivots above WMF_PIVOT_CAP bounce the row)
                 float yp = yacc[S];
                 yp = wmf_qsum(yp);
                 float wv0 = X[0] * yp, wv1 = X[1] * yp, wv2 = X[2] * yp, wv3 = X[3] * yp;

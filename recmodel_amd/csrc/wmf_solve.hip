@@ -291,10 +291,17 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
     if constexpr (BLK && NSETS == 2) {
 #endif
         // ---- symmetric form and 2 x 2 block elimination with 16 x 16 tiles:
-        //   c = p - E y,   (I + E S E) y = E S p,   E = diag(sqrt(w))        (equal to (I + D S)^-1 p)
+        //   c = E y,   (I + E S E) y = E^-1 p,   E = diag(sqrt(w))        (I + D S = E (I + E S E) E^-1)
         //   P = [[A, U], [B, C]],  B = U^T:  X = A^-1 (tile Gauss-Jordan), T = B X and S' = C - T B^T by MFMA on the
         //   row-distributed registers (MFMA(RD(X), RD(Y)) = RD(Y X^T)), then two tile solves for the vectors.
-        const float e0 = __builtin_amdgcn_sqrtf(w[0]), e1 = __builtin_amdgcn_sqrtf(w[1]);   // raw v_sqrt_f32 (1 ulp): E only has to satisfy E^2 ~ D
+        // (Round 3: this replaces  c = p - E y', (I + E S E) y' = E S p,  whose last step subtracts two numbers of the size of
+        // w to get a c of order one -- exact enough at w ~ 10, a relative error of 6e-8 w / c beyond: wrong rows for
+        // confidence weights of 1e4 and more, tests/test_gpu_parity.py::test_weight_range_of_the_class_surface.)
+        // A weight of zero -- a stored zero, which still contributes p = 1 (wmf_model.py:232,239), or a slot past the row's end
+        // (p = 0) -- has no E^-1: it is taken as 1e-30, whose row of P is an identity row to 1e-15: y = 1e15 p there and
+        // c = E y = p, exactly what the row of I + D S says.
+        const float wc0 = fmaxf(w[0], 1e-30f), wc1 = fmaxf(w[1], 1e-30f);
+        const float e0 = __builtin_amdgcn_sqrtf(wc0), e1 = __builtin_amdgcn_sqrtf(wc1);   // raw v_sqrt_f32 (1 ulp): E only has to satisfy E^2 ~ D
         const int caddr[4] = {(4 * q + 0) * 4, (4 * q + 1) * 4, (4 * q + 2) * 4, (4 * q + 3) * 4};   // lane of entry 4q + reg (q = 0 row)
         auto col4 = [&](float v, float (&out)[4]) {             // out[reg] = value of row 4q + reg
 #pragma unroll
@@ -302,25 +309,20 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
                 out[reg] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(caddr[reg], __builtin_bit_cast(int, v)));
         };
         auto qsum = [&](float v) { return wmf_qsum(v); };
-        float eA[4], eB[4], pA[4], pB[4];
+        float eA[4], eB[4];
         col4(e0, eA);
         col4(e1, eB);
-        col4(p[0], pA);                                          // 0 for the slots past the row's end, whose S entries are not
-        col4(p[1], pB);
         f32x4 PA, PU, PB, PC;
-        float spA = 0.f, spB = 0.f;                              // (S p) of my A row / my B row, partial over my columns
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            spA += Sb[0][0][reg] * pA[reg] + Sb[0][1][reg] * pB[reg];
-            spB += Sb[1][0][reg] * pA[reg] + Sb[1][1][reg] * pB[reg];
             const float dg = (r == 4 * q + reg) ? 1.f : 0.f;
             PA[reg] = dg + e0 * Sb[0][0][reg] * eA[reg];
             PU[reg] = e0 * Sb[0][1][reg] * eB[reg];
             PB[reg] = e1 * Sb[1][0][reg] * eA[reg];
             PC[reg] = dg + e1 * Sb[1][1][reg] * eB[reg];
         }
-        const float tA = e0 * qsum(spA);
-        float tB = e1 * qsum(spB);
+        const float tA = p[0] * __builtin_amdgcn_rsqf(wc0);      // E^-1 p
+        float tB = p[1] * __builtin_amdgcn_rsqf(wc1);
         bool okb = true;
         f32x4 X = PA;
         gj_inv_sweep<true, false>(X, baddr, r, q, okb, std::make_integer_sequence<int, 16>{});   // w >= 0: I + E S_AA E is SPD, pivots >= 1
@@ -341,8 +343,8 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
         const float z = tA - qsum(PU[0] * col[0] + PU[1] * col[1] + PU[2] * col[2] + PU[3] * col[3]);
         col4(z, col);
         const float yA = qsum(X[0] * col[0] + X[1] * col[1] + X[2] * col[2] + X[3] * col[3]);
-        p[0] -= e0 * yA;
-        p[1] -= e1 * yB;
+        p[0] = e0 * yA;
+        p[1] = e1 * yB;
         if (!okb) p[0] = __builtin_nanf("");                     // caught by the finite check below
     } else {
         // ---- M = I + D S row-distributed: m[s][c*4 + reg] = M[row r + 16 s][col 16 c + 4 q + reg]; Gauss-Jordan
@@ -825,6 +827,7 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
         side = biasv;
         bstride = 2;
     } else if (biasv) {                                                // other widths: fold the biases into the weights once
+        if (!pl->w_eff) return -3;                                     // (plan latched the split layout, this call is not in it)
         wmf_launch_bias_adjust(vals, indices, biasv, nnz, pl->w_eff, st);   // (w_eff: allocated by wmf_plan_create(bias = 1))
         vals = pl->w_eff;
         biasv = nullptr;
@@ -836,7 +839,11 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
         default: return -1;
     }
     const bool general_ok = f <= 144;
-    if (pl->count[WMF_BIN_MFMA] > 0) {
+    if (pl->count[WMF_BIN_MFMA] > 0 && (wmf_debug_flags & 33554432)) {
+        // debug flag 33554432 (accuracy experiments): every row of this bin through the pivoted float32 LU kernel
+        if (dispatch_general(pl->rows[WMF_BIN_MFMA], pl->count[WMF_BIN_MFMA], nullptr, 256, V, biasv, bstride, indptr, indices, vals, f, ld,
+                             g, fail_count, st)) return -1;
+    } else if (pl->count[WMF_BIN_MFMA] > 0) {
         // one wave per row with the whole system in MFMA accumulator registers (wmf_directw.hip, wmf_directl.hip)
         if (wmf_launch_directw(pl, V, side, indptr, indices, vals, f, ld, g, st)) return -1;
     }

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(512, 1) void solve_wide_kernel(const int32_t* __res
                 if (ti[a] == p && tj[a] == p) {
                     f32x4 X = acc[a];
                     bool ok = true;
-                    gj_inv_sweep(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});
+                    gj_inv_sweep<true, true, true>(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});   // (pivots above WMF_PIVOT_CAP bounce the row)
                     if (!ok && lane == 0) flag[0] = 1;
                     *reinterpret_cast<float4*>(T + p * 320 + r * 20 + 4 * q) = make_float4(X[0], X[1], X[2], X[3]);
                 }

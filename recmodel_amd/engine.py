@@ -160,7 +160,8 @@ class HipKernels:
 class Csr:
     """CSR shard resident in HBM (int64 indptr, int32 indices, fp32 values) plus its row plan."""
 
-    def __init__(self, kernels, indptr, indices, values, n_cols, f, bias=False):
+    def __init__(self, kernels, indptr, indices, values, n_cols, f, bias=False, plan=True):
+        """plan=False: a shard that is only read by eval_sums (no row solve): no row plan, none of its device buffers."""
         self.kernels = kernels
         self.indptr = indptr.to(torch.int64).contiguous()
         self.indices = indices.to(torch.int32).contiguous()
@@ -169,6 +170,9 @@ class Csr:
         self.n_cols = int(n_cols)
         self.nnz = int(self.indices.numel())
         self.f = f
+        if not plan:
+            self._plan = None
+            return
         host_ptr = np.ascontiguousarray(self.indptr.cpu().numpy(), dtype=np.int64)
         self._plan, stats = kernels.plan_create(host_ptr, self.n_rows, f, bias)
         self.bin_rows, self.bin_nnz = stats[:4].copy(), stats[4:8].copy()
@@ -593,12 +597,12 @@ class AlsEngine:
         w_eff = torch.empty_like(v) if self.bias and not self.split else None    # (split layout: the kernels take the bias with the row)
         return indptr.contiguous(), deg, idx.contiguous(), v.contiguous(), w_eff
 
-    def _shard(self, side, rows, cols, vals):
+    def _shard(self, side, rows, cols, vals, plan=True):
         """CSR of this rank's rows of ``side`` (all of them its own already): local row x gathered position of the column."""
         other = self._other(side)
         local = self.shard[side].local_of(rows)
         indptr, idx, v = coo_to_csr(local, self.positions(other, cols), vals, self.rpr[side], self.K, self.world * self.rpr[other])
-        return Csr(self.K, indptr, idx, v, self.world * self.rpr[other], self.f, self.bias)
+        return Csr(self.K, indptr, idx, v, self.world * self.rpr[other], self.f, self.bias, plan=plan)
 
     def set_factors(self, side, full):
         """Load a full host/device [n, f] factor matrix (reference layout) into this rank's block."""
@@ -721,8 +725,9 @@ class AlsEngine:
                             bvec[rows] if self.bias else None)
             K.accumulate_rows(V, bvec if self.bias else None, ptr, deg, idx, val, n, idx.numel(), self.f, self.ld,
                               self.partial_pipe[side], w_eff, slot_stride=C, slot_offset=c)
+        before = self._fail_snapshot()
         K.eliminate_rows(self.partial_pipe[side], n, self.f, self.ld, self.g[side], self.fail, self.scratch_rows, slots_per_row=C)
-        if self._summed_system_failed():
+        if self._summed_system_failed(before):
             return self._redo_through_gather(side)
         K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, False, self.factors[side], None)
         self.has_factors[side] = True
@@ -755,27 +760,35 @@ class AlsEngine:
         for w in works:
             if w is not None:
                 w.wait()
+        before = self._fail_snapshot()
         K.eliminate_rows(self.partial_mine[side], self.rpr[side], self.f, self.ld, self.g[side], self.fail, self.scratch_rows)
-        if self._summed_system_failed():
+        if self._summed_system_failed(before):
             return self._redo_through_gather(side)
         K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, False, self.factors[side], None)
         self.has_factors[side] = True
         for c in range(len(self.chunk_bounds[side])):
             self._publish(side, c)
 
-    def _summed_system_failed(self):
+    def _fail_snapshot(self):
+        """The sticky failure counter as it stands before an eliminate pass (bias models only; None otherwise)."""
+        return self.fail[:1].clone() if self.bias else None
+
+    def _summed_system_failed(self, before):
         """Bias models in reduce / pipelined mode: did any rank meet a row whose summed system is not positive definite
-        (negative bias-adjusted weights)?  One small all-reduce and one host sync per half step -- the price of letting
-        bias models use the two modes; models without biases never ask (their systems are positive definite by
+        (negative bias-adjusted weights) IN THE ELIMINATE PASS JUST ENQUEUED?  ``before`` is the counter's value in front of
+        that pass: the counter is sticky and also holds what the previous half step left (a singular row of the gather path's
+        pivoted kernel is only looked at once per iteration, in check_numerics) -- such a count is neither taken for a failure
+        of this pass nor lost: only the delta is cleared.  One small all-reduce and one host sync per half step -- the price of
+        letting bias models use the two modes; models without biases never ask (their systems are positive definite by
         construction)."""
         if not self.bias:
             return False
-        flag = self.fail[:1].clone()
+        flag = self.fail[:1] - before
         if self.exchange:
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=self.group)
         if int(flag.item()) == 0:
             return False
-        self.fail.zero_()                            # those rows are solved again below, by kernels that can pivot
+        self.fail[:1].copy_(before)                  # those rows are solved again below, by kernels that can pivot
         return True
 
     def _redo_through_gather(self, side):
@@ -843,7 +856,7 @@ class AlsEngine:
         if self.world > 1:
             m = self.shard["users"].owner_of(rows) == self.rank
             rows, cols, vals = rows[m], cols[m], vals[m]
-        return self._shard("users", rows, cols, vals)
+        return self._shard("users", rows, cols, vals, plan=False)
 
     def make_eval_shard_distributed(self, first_user, indptr, indices, values):
         """make_eval_shard from this rank's block of user rows (set_interactions_distributed): every entry travels to the
@@ -856,7 +869,7 @@ class AlsEngine:
         rows = first_user + torch.repeat_interleave(torch.arange(indptr.numel() - 1, device=dev), counts)
         if self.world > 1:
             rows, cols, vals = self._exchange(self.shard["users"].owner_of(rows), (rows, cols, vals))
-        return self._shard("users", rows, cols, vals)
+        return self._shard("users", rows, cols, vals, plan=False)
 
     def eval_sums(self, shard):
         """(sum of squared errors, sum of absolute errors, count) over the stored non-zero entries

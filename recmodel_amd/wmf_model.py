@@ -358,14 +358,19 @@ class WMF(RecModel):
             raise ValueError(f"Values of cores has to be positive not {cores}")
         if self.bias is not True and self.bias is not False:
             raise ValueError(f"self.bias = {self.bias} is unknown. Only True / False are allowed.")
-        indptr, indices, values = _csr_parts(count_mat)
-        values = values.to(eng.device)
-        eng.K.confidence_transform(values, alpha, beta, 0 if pre_process_count == 'log' else 1)
-        eng.set_interactions(indptr, indices, values)      # also builds the item-major shard (:128)
-        # cores > 1 with a float64 count matrix: the reference's Pool variants keep float64 rows (:242-265), so its
-        # training continues on float64 factors -- the float64 device path then does the half steps, the engine only the MSE
-        f64 = _Float64Steps(self, eng, count_mat, alpha, beta, pre_process_count) \
-            if cores > 1 and np.dtype(count_mat.dtype) == np.float64 else None
+        # cores > 1 with a float64 OR INTEGER count matrix: the reference's Pool variants keep float64 rows (:242-265) -- the
+        # confidence transform of integer counts is float64 ('log', :120) or int64 ('linear', :123; the row products then
+        # promote) -- so its training continues on float64 factors: the float64 device path then does the half steps, the
+        # engine only the MSE (and builds neither float32 shards nor row plans).  float32 / float16 counts stay float32.
+        cdt = np.dtype(count_mat.dtype)
+        f64 = None
+        if cores > 1 and (cdt.kind in 'iub' or cdt == np.float64):
+            f64 = _Float64Steps(self, eng, count_mat, alpha, beta, pre_process_count)
+        else:
+            indptr, indices, values = _csr_parts(count_mat)
+            values = values.to(eng.device)
+            eng.K.confidence_transform(values, alpha, beta, 0 if pre_process_count == 'log' else 1)
+            eng.set_interactions(indptr, indices, values)      # also builds the item-major shard (:128)
         eval_shard = self._train_eval_shard(eng, eval_mat)
         train_shard = eng.make_eval_shard(*_csr_parts(utility_mat)) if verbose > 1 else None
 

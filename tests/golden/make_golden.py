@@ -220,7 +220,34 @@ def make_train_par(WMF):
     print("train_par.npz", os.path.getsize(f"{OUT}/train_par.npz"))
 
 
+def make_train_par_int(WMF):
+    """cores = 2 on an INTEGER count matrix (round 3): `alpha * np.log(1 + beta * data)` of int64 data is float64
+    (wmf_model.py:120), and with 'linear' the int64 weights promote the row products to float64 (:123, :285-287) -- either
+    way the Pool variants return float64 rows and training continues on float64 factors."""
+    counts = make_counts(90, 50, 5, seed=61, dtype="float64")
+    counts = sp.csr_matrix((np.rint(counts.data).astype(np.int64), counts.indices, counts.indptr), shape=counts.shape)
+    util = counts.astype(np.float64)
+    util.data = np.minimum(util.data, 5.0)
+    out = {}
+    for mode in ("log", "linear"):
+        mdl = WMF(num_items=50, num_users=90, dim=6, gamma=0.1, weighted=True, bias=(mode == "linear"), seed=1993)
+        last = mdl.train(utility_mat=util, iterations=2, verbose=0, eval_mat=util, count_mat=counts, cores=2,
+                         stopping_rounds=5, pre_process_count=mode, alpha=(10 if mode == "log" else 2))
+        assert mdl.users.dtype == np.float64 and mdl.items.dtype == np.float64
+        out[f"last_iter_{mode}"] = last
+        out[f"mse_final_{mode}"] = mdl.eval_prec(util)
+        out[f"users_{mode}"] = mdl.users
+        out[f"items_{mode}"] = mdl.items
+    out.update(csr_fields("counts", counts))
+    out.update(csr_fields("util", util))
+    np.savez_compressed(f"{OUT}/train_par_int.npz", **out)
+    print("train_par_int.npz", os.path.getsize(f"{OUT}/train_par_int.npz"))
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["train_par_int"]:                # only the file added in round 3
+        make_train_par_int(load_reference())
+        sys.exit(0)
     if sys.argv[1:] == ["train_par"]:                    # only the file added in round 2 (the others stay byte-identical)
         make_train_par(load_reference())
         sys.exit(0)

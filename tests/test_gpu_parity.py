@@ -424,7 +424,9 @@ def test_weight_range_of_the_class_surface(WMF, k, bias, mode):
     record_error(f"weight_range[k={k},bias={int(bias)},{mode}]", worst_row=e_got.max(), worst_row_numpy_f32=e_ref.max(),
                  median_row=float(np.median(e_got)), median_row_numpy_f32=float(np.median(e_ref)),
                  rows_above_tolerance=int((e_got > tol_row).sum()), rows_numpy_f32_above_tolerance=int((e_ref > tol_row).sum()))
-    assert not bad.any(), (k, bias, mode, int(bad.sum()), e_got[bad][:5], e_ref[bad][:5], degs[ok][bad][:5])
+    wmax = np.array([C.data[C.indptr[r]: C.indptr[r + 1]].max(initial=0.0) for r in range(n)])[ok]
+    table = sorted(zip(degs[ok][bad].tolist(), wmax[bad].tolist(), e_got[bad].tolist(), e_ref[bad].tolist()))
+    assert not bad.any(), (k, bias, mode, int(bad.sum()), [f"d={d} wmax={w_:.1e} gpu={a:.1e} numpy32={b:.1e}" for d, w_, a, b in table])
     assert not got[degs == 0].any()
 
 
@@ -530,6 +532,26 @@ def test_train_cores2_float64_vs_reference_golden(WMF):
     # a float32 count matrix keeps the reference's Pool variants in float32
     model = WMF(num_items=util.shape[1], num_users=util.shape[0], dim=8, gamma=0.1, weighted=True)
     model.train(utility_mat=util, iterations=1, eval_mat=util, count_mat=counts.astype(np.float32), cores=2, stopping_rounds=5)
+    assert model.users.dtype == np.float32
+
+
+def test_train_cores2_integer_counts_vs_reference_golden(WMF):
+    """An int64 count matrix with cores = 2: float64 factors in the reference ('log': the transform is float64; 'linear': int64
+    weights promote the row products) -- golden train_par_int.npz from the reference itself."""
+    g = load_golden("train_par_int.npz")
+    counts, util = csr_from(g, "counts"), csr_from(g, "util")
+    assert counts.dtype == np.int64
+    for mode in ("log", "linear"):
+        model = WMF(num_items=util.shape[1], num_users=util.shape[0], dim=6, gamma=0.1, weighted=True, bias=(mode == "linear"))
+        last = model.train(utility_mat=util, iterations=2, eval_mat=util, count_mat=counts, cores=2, stopping_rounds=5,
+                           pre_process_count=mode, alpha=(10 if mode == "log" else 2))
+        assert last == int(g[f"last_iter_{mode}"])
+        assert model.users.dtype == np.float64 and model.items.dtype == np.float64
+        assert fro(model.users, g[f"users_{mode}"]) <= 2e-5 and fro(model.items, g[f"items_{mode}"]) <= 2e-5
+        assert abs(model.eval_prec(util) - float(g[f"mse_final_{mode}"])) <= 1e-5 * float(g[f"mse_final_{mode}"])
+    # cores = 1 on the same matrix: float32 factors (recompute_factors casts each row back, :217, :239)
+    model = WMF(num_items=util.shape[1], num_users=util.shape[0], dim=6, gamma=0.1, weighted=True)
+    model.train(utility_mat=util, iterations=1, eval_mat=util, count_mat=counts, cores=1, stopping_rounds=5)
     assert model.users.dtype == np.float32
 
 

@@ -164,3 +164,18 @@ def test_solve_row_in_slabs_equals_solve_row():
     want = orc.solve_row(G, Y, idx, w)
     slabs = [(Y[idx[lo: lo + 100]], w[lo: lo + 100]) for lo in range(0, 333, 100)]
     np.testing.assert_allclose(orc.solve_row_in_slabs(G, slabs), want, rtol=1e-12, atol=1e-14)
+
+
+def test_train_cores2_on_integer_counts_is_float64():
+    """Golden from the reference (make_golden.py train_par_int): an int64 count matrix with cores = 2 leaves float64 factors,
+    with 'log' (the transform itself is float64) and with 'linear' (int64 weights promote the row products)."""
+    g = load_golden("train_par_int.npz")
+    counts, util = csr_from(g, "counts"), csr_from(g, "util")
+    assert counts.dtype == np.int64
+    for mode in ("log", "linear"):
+        last, hist, users, items = orc.train(50, 90, 6, 0.1, util, 2, util, count_mat=counts, weighted=True, bias=(mode == "linear"),
+                                             stopping_rounds=5, cores=2, pre_process_count=mode, alpha=(10 if mode == "log" else 2))
+        assert last == int(g[f"last_iter_{mode}"]) and users.dtype == np.float64 and items.dtype == np.float64
+        np.testing.assert_allclose(users, g[f"users_{mode}"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(items, g[f"items_{mode}"], rtol=RTOL, atol=ATOL)
+        assert abs(hist[-1] - float(g[f"mse_final_{mode}"])) <= 1e-6 * float(g[f"mse_final_{mode}"])
