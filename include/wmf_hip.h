@@ -206,7 +206,7 @@ int wmf_confidence_transform_f64(double* values, int64_t nnz, double alpha, doub
  * point is that arithmetic on the device, without the whitening of the float32 path: Gramian in float64, then per row
  * the system accumulated and factored in registers, one workgroup per row (blocked Cholesky; a system that is not positive
  * definite -- bias-adjusted weights below zero -- or not finite is redone by LU with partial pivoting, np.linalg.solve's
- * gesv); both agree with the float64 oracle to 1e-10.
+ * gesv); both agree with the float64 reference arithmetic to 1e-10.
  *   Y [m, f] float64 row-major (dense, no padding), values float64[nnz], X [n, f] float64 out, all on the device;
  *   workspace: wmf_half_step_f64_workspace_bytes(f, m, n) bytes; fail_count (device int32, caller zeroes): += 1 per
  *   exactly singular row system (its X row is NaN; the reference raises LinAlgError).  Enqueues only. */

@@ -216,21 +216,24 @@ __device__ __forceinline__ float wmf_qsum(float v) {
 // The multiplier A[r][K] sits in lane (r, K / 4); LDS = true fetches it with one ds_bpermute (one LDS instruction,
 // long latency), false with two VALU lane swaps (five VALU instructions, no LDS round trip).
 // CHECK = false skips the pivot test: for callers whose tile is positive definite by construction (pivots >= 1)
-// and who test the result for NaN / Inf anyway.  CAP: a pivot above WMF_PIVOT_CAP also clears `ok` -- for the block
-// eliminations that multiply by the explicit inverse of the pivot tile: that is as accurate as a triangular solve only while
-// the tile is well conditioned (errors grow with cond(tile)^2, and the split-f16 parts of 1 / piv lose bits to the f16
-// subnormal range as piv grows).  Whitened systems under the usual confidence weights have pivots in [1, 1 + max w] -- 20 for
-// alpha = 10, 'log', counts up to 6 -- so the cap never fires there; a row that carries weights of 1e3 and more (alpha * count,
-// 'linear') goes to the pivoted LU kernel instead, which is slower and as accurate as float32 allows (measured on MI355X,
-// tests/scale/diag_weights_mixed.py: 1e-3 at cond 1e4 where the tile-inverse path gave 0.1 .. 0.5).
-#define WMF_PIVOT_CAP 32.f
+// and who test the result for NaN / Inf anyway.  CAP: a tile whose pivots spread over more than a factor WMF_PIVOT_SPREAD
+// (or exceed WMF_PIVOT_CAP) also clears `ok` -- for the block eliminations that multiply by the explicit inverse of the pivot
+// tile: that is as accurate as a triangular solve only while the tile is well conditioned (errors grow with cond(tile)^2;
+// the pivot spread is the cheap proxy for cond(tile)), and the split-f16 parts of 1 / piv lose bits to the f16 subnormal
+// range as piv grows.  Whitened systems under the usual confidence weights have tile pivots within a factor of two or three of
+// each other -- 1.0 .. 1.3 on the benchmark matrices, 3 .. 11 in the 7 M-entry item rows of their Zipf variants -- so neither
+// test fires there; a row that MIXES weights of 1e4 and more with ordinary ones (alpha * count, 'linear') goes to the pivoted LU
+// kernel instead, which is slower and as accurate as float32 allows (measured on MI355X, tests/scale/diag_weights_mixed.py:
+// 1e-3 at cond 1e4 where the tile-inverse path gave 0.1 .. 0.5).
+#define WMF_PIVOT_CAP 256.f
+#define WMF_PIVOT_SPREAD 8.f
 template <int K, bool LDS, bool CHECK, bool CAP = false>
-__device__ __forceinline__ void gj_inv_step(f32x4& a, float& dsc, const int (&baddr)[4], int r, int q, bool& ok) {
+__device__ __forceinline__ void gj_inv_step(f32x4& a, float& dsc, const int (&baddr)[4], int r, int q, bool& ok, float& plo, float& phi) {
     constexpr int kq = K >> 2, kr = K & 3;
     const float akr = a[kr];     // copy first: __builtin_bit_cast applied to the vector-element lvalue itself reads element 0
     const float piv = rlw(akr, K + 16 * kq);
     if constexpr (CHECK) { if (!(piv > 1e-20f)) ok = false; }
-    if constexpr (CAP) { if (piv > WMF_PIVOT_CAP) ok = false; }
+    if constexpr (CAP) { plo = fminf(plo, piv); phi = fmaxf(phi, piv); }       // (wave-uniform values: scalar arithmetic)
     const float inv = __builtin_amdgcn_rcpf(piv);
     float fk;
     if constexpr (LDS) fk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(baddr[kq], __builtin_bit_cast(int, akr)));
@@ -245,8 +248,9 @@ __device__ __forceinline__ void gj_inv_step(f32x4& a, float& dsc, const int (&ba
 template <bool LDS = true, bool CHECK = true, bool CAP = false, int... Ks>
 __device__ __forceinline__ void gj_inv_sweep(f32x4& a, const int (&baddr)[4], int r, int q, bool& ok,
                                              std::integer_sequence<int, Ks...>) {
-    float dsc = 1.f;
-    (gj_inv_step<Ks, LDS, CHECK, CAP>(a, dsc, baddr, r, q, ok), ...);
+    float dsc = 1.f, plo = 3.0e38f, phi = 0.f;
+    (gj_inv_step<Ks, LDS, CHECK, CAP>(a, dsc, baddr, r, q, ok, plo, phi), ...);
+    if constexpr (CAP) { if (phi > WMF_PIVOT_CAP || phi > WMF_PIVOT_SPREAD * plo) ok = false; }
     a *= dsc;
 }
 
@@ -299,12 +303,17 @@ __device__ __forceinline__ void gj_inv_step_lean(f32x4& a, float& dsc, int& pmin
 }
 // (the caller multiplies the swept tile by dsc: X = diag(dsc) . a)
 template <bool BP = false, int... Ks>
-__device__ __forceinline__ void gj_inv_sweep_lean(f32x4& a, float& dsc, int& pmin, int& pmax, int r4, std::integer_sequence<int, Ks...>) {
+__device__ __forceinline__ void gj_inv_sweep_lean(f32x4& a, float& dsc, int& pmin, int& pmax, int& spread, int r4, std::integer_sequence<int, Ks...>) {
     dsc = 1.f;
-    (gj_inv_step_lean<Ks, BP>(a, dsc, pmin, pmax, r4), ...);
+    int tlo = 0x7f800000, thi = 0;                                   // this tile's smallest / largest pivot (bit patterns)
+    (gj_inv_step_lean<Ks, BP>(a, dsc, tlo, thi, r4), ...);
+    pmin = min(pmin, tlo);
+    pmax = max(pmax, thi);
+    spread = max(spread, thi - tlo);                                 // positive floats: the difference of the bit patterns ~ 2^23 log2(ratio)
 }
 #define WMF_PIVOT_MIN_BITS 0x1e3ce508
-#define WMF_PIVOT_CAP_BITS 0x42000000          /* 32.f = WMF_PIVOT_CAP */
+#define WMF_PIVOT_CAP_BITS 0x43800000          /* 256.f = WMF_PIVOT_CAP */
+#define WMF_PIVOT_SPREAD_BITS (3 << 23)         /* a factor 8 = WMF_PIVOT_SPREAD between a tile's pivots */
 
 // The same inverse as a SYMMETRIC sweep whose rank-one update is one f32 MFMA -- for callers that run two waves per SIMD and
 // are bound by VALU issue, with MFMA time to spare.  The tile stays symmetric, so the row-distributed layout above is also

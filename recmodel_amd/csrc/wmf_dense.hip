@@ -19,7 +19,7 @@ __device__ __forceinline__ void gram_body(const float* __restrict__ Y, int64_t m
                                           float* __restrict__ partial, int64_t step_lo, int64_t step_hi) {
     constexpr int NT = NFB * (NFB + 1) / 2;
     constexpr int NACC = (NT + NSPLIT - 1) / NSPLIT;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;                           // (NSPLIT = 4: the four waves of a workgroup, one tile quarter each)
     const int r = lane & 15, q = lane >> 4;
     f32x4 acc[NACC];
 #pragma unroll
@@ -168,8 +168,11 @@ __global__ __launch_bounds__(64) void gram6_kernel(const float* __restrict__ Y, 
     gram_body6<NFB>(Y, m, f, ld, bias, partial, blockIdx.x, gridDim.x);
 }
 
+// NSPLIT = 4 (f > 144: 136 tiles do not fit one wave's registers): the tile quarters are the FOUR WAVES OF ONE WORKGROUP, which
+// walk the same rows at the same time -- one of them brings a row in from HBM, the other three find it in the CU's L1 / L2
+// (round 2 launched the quarters as four separate workgroups: 8.26 GB of counted traffic for a 2.05 GB matrix at cfg5s).
 template <int NFB, int NSPLIT>
-__global__ __launch_bounds__(64) void gram_kernel(const float* __restrict__ Y, int64_t m, int f, int ld, int bias,
+__global__ __launch_bounds__(NSPLIT == 1 ? 64 : 256) void gram_kernel(const float* __restrict__ Y, int64_t m, int f, int ld, int bias,
                                                   float* __restrict__ partial, int64_t steps_per_wave) {
     const int64_t nsteps = (m + 3) / 4;
     int64_t lo = (int64_t)blockIdx.x * steps_per_wave;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(64) void gram_kernel(const float* __restrict__ Y, i
     if constexpr (NSPLIT == 1) {
         gram_body<NFB, 1, 0>(Y, m, f, ld, bias, partial, lo, hi);
     } else {
-        switch (blockIdx.y) {
+        switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
             case 0: gram_body<NFB, NSPLIT, 0>(Y, m, f, ld, bias, partial, lo, hi); break;
             case 1: gram_body<NFB, NSPLIT, 1>(Y, m, f, ld, bias, partial, lo, hi); break;
             case 2: gram_body<NFB, NSPLIT, 2>(Y, m, f, ld, bias, partial, lo, hi); break;
@@ -237,7 +240,7 @@ static int launch_gram_nfb(const float* Y, int64_t m, int f, int ld, int bias, f
         WMF_LAUNCH(nm, (gram_kernel<NFB, 1>), dim3(nwaves), dim3(64), 0, st, Y, m, f, ld, bias, partial, spw);
     } else {
         static const char* nm = wmf_kname("gram_kernel<%d, 4>", NFB);
-        WMF_LAUNCH(nm, (gram_kernel<NFB, 4>), dim3(nwaves, 4), dim3(64), 0, st, Y, m, f, ld, bias, partial, spw);
+        WMF_LAUNCH(nm, (gram_kernel<NFB, 4>), dim3(nwaves), dim3(256), 0, st, Y, m, f, ld, bias, partial, spw);
     }
     return 0;
 }

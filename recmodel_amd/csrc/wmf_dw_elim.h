@@ -119,7 +119,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(base + (16 * p + 4 * q) * 4) : "memory");
         return v;
     };
-    int pmin = 0x7f800000, pmax = 0;                             // wave-uniform: smallest / largest pivot of the tile inverses (bit patterns)
+    int pmin = 0x7f800000, pmax = 0, spread = 0;                 // wave-uniform: smallest / largest pivot of the tile inverses (bit patterns), largest spread within a tile
     float cacc2 = 0.f, eacc2 = 0.f;                              // BORDER: per-lane parts of the two border sums
     // ---- C: block elimination, everything in registers except the two panel buffers
     if (!WMF_ABL(dbg, 1)) {
@@ -144,7 +144,7 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
                     X = -X;
                 } else if (!WMF_ABL(dbg, 8)) {
                     float dsc = 1.f;                                 // un-normalised sweep (wmf_common.h): X = diag(dsc) . tile
-                    gj_inv_sweep_lean<(RELANE && WMF_DW_BP != 0)>(X, dsc, pmin, pmax, 4 * r, std::make_integer_sequence<int, 16>{});
+                    gj_inv_sweep_lean<(RELANE && WMF_DW_BP != 0)>(X, dsc, pmin, pmax, spread, 4 * r, std::make_integer_sequence<int, 16>{});
                     X *= dsc;
                 }
                 if (diag != 1.f) X *= 1.f / diag;
@@ -323,9 +323,9 @@ __device__ __forceinline__ void dw_eliminate(f32x4 (&acc)[NFB * (NFB + 1) / 2], 
     if constexpr (!GJ_LDS) {
         // the lean sweep's pivot test lets a NaN through (wmf_common.h): it is in the solution now
         bool bad = !(pmin > WMF_PIVOT_MIN_BITS);
-        // pivots above WMF_PIVOT_CAP (confidence weights far above the usual range): the row goes to the pivoted LU kernel
-        // (wmf_common.h, gj_inv_step)
-        bad |= pmax > WMF_PIVOT_CAP_BITS;
+        // a tile with pivots far apart, or above WMF_PIVOT_CAP (rows that mix confidence weights far above the usual range with
+        // ordinary ones): the row goes to the pivoted LU kernel (wmf_common.h, gj_inv_step)
+        bad |= pmax > WMF_PIVOT_CAP_BITS || spread > WMF_PIVOT_SPREAD_BITS;
 #pragma unroll
         for (int p = 0; p < NFB; ++p) bad |= !(fabsf(gb[p]) < 3.0e38f);
         if constexpr (BORDER) bad |= !(fabsf(tb) < 3.0e38f);

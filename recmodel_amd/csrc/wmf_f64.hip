@@ -18,7 +18,7 @@
 //       factorisation ends), and the back substitution R x = y walks the block columns again with each R block still in the
 //       registers of its owner.  Two barriers per block column and phase, no workspace.
 //       np.linalg.solve is LU with partial pivoting; for a positive definite system Cholesky gives the same solution to a
-//       few ulp of float64 (the tests hold both to 1e-10 of the oracle).
+//       few ulp of float64 (the tests hold both to 1e-10 of the float64 reference arithmetic).
 //   solve64_lu_kernel      rows whose system is NOT positive definite (bias-adjusted weights below zero, :279) or not finite:
 //       the factorisation above meets a non-positive pivot and hands the row over -- LU with partial pivoting (first maximum as
 //       idamax, i.e. gesv), the right-hand side carried along, the row system in an L2-resident workspace slice; an exactly
@@ -124,42 +124,67 @@ __global__ __launch_bounds__(256) void gram64v2_reduce_kernel(const double* __re
     G[(int64_t)gj * f + gi] = s;
 }
 
-// ---- one row system per workgroup, in registers from the first gathered entry to the solution --------------------------------
-// Dynamic LDS (doubles): ys [F64_R][FP + 4] | wv [F64_R] | pv [F64_R] | panel [2][(f4 + 1) * 16] | dbuf [2][16] | yv [FP] |
-// xs [4] | ib (int) [F64_R] + flag
-static size_t solve64v2_lds_bytes(int f) {
-    const int f4 = (f + 3) / 4, FP = 4 * f4;
-    return (size_t)(F64_R * (FP + 4) + 2 * F64_R + 2 * (f4 + 1) * 16 + 32 + FP + 4) * 8 + (F64_R + 4) * 4;
+// ---- one row system per TEAM, in registers from the first gathered entry to the solution ---------------------------------
+// TEAM = 256: the whole workgroup works on one row (barriers are __syncthreads).  TEAM = 64 (f <= 68: at most three blocks per
+// lane): every WAVE of the workgroup has its own row and its own slice of LDS, and the steps below are ordered by the wave's
+// lockstep execution (a wave-scope fence instead of a workgroup barrier) -- four rows in flight per workgroup where a narrow
+// system would leave most of 256 threads without a block and every step waiting on a barrier.
+// Dynamic LDS per team (doubles): ys [R][FP + 4] | wv [R] | pv [R] | panel [2][(f4 + 1) * 16] | dbuf [2][16] | yv [FP] | xs [4] |
+// ib (int) [R] + flag
+template <int TEAM> __device__ __forceinline__ void f64_team_sync() {
+    if constexpr (TEAM == 256) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 }
-template <int NB>
+static size_t solve64v2_team_doubles(int f, int R) {
+    const int f4 = (f + 3) / 4, FP = 4 * f4;
+    return (size_t)(R * (FP + 4) + 2 * R + 2 * (f4 + 1) * 16 + 32 + FP + 4) + (size_t)(R + 4 + 1) / 2 + 1;
+}
+// 1 / sqrt(x) to float64 accuracy from the hardware estimate (v_rsq_f64, ~2^-26) and two Newton steps; x > 0
+__device__ __forceinline__ double f64_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double h = 0.5 * y, e = __builtin_fma(-x * y, y, 1.0);     // 1 - x y^2
+        y = __builtin_fma(h, e, y);
+    }
+    return y;
+}
+template <int NB, int TEAM, int R>
 __global__ __launch_bounds__(256) void solve64v2_kernel(const double* __restrict__ Y, int f, int bias, const double* __restrict__ G,
                                                         const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                         const double* __restrict__ vals, int64_t n, double* __restrict__ X,
-                                                        int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count) {
+                                                        int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int team_doubles) {
     extern __shared__ __attribute__((aligned(16))) double sm64[];
-    const int t = threadIdx.x;
+    constexpr int NTEAM = 256 / TEAM;
+    const int t = threadIdx.x & (TEAM - 1);
+    const int tw = TEAM == 256 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int f4 = (f + 3) >> 2, FP = 4 * f4, FPA = FP + 4, nblk = f4 * (f4 + 1) / 2 + f4;
-    double* ys = sm64;
-    double* wv = ys + F64_R * FPA;
-    double* pv = wv + F64_R;
-    double* panel = pv + F64_R;
+    double* ys = sm64 + (size_t)tw * team_doubles;
+    double* wv = ys + R * FPA;
+    double* pv = wv + R;
+    double* panel = pv + R;
     double* dbuf = panel + 2 * (f4 + 1) * 16;
     double* yv = dbuf + 32;
     double* xs = yv + FP;
     int* ib = reinterpret_cast<int*>(xs + 4);
-    int* flag = ib + F64_R;
+    int* flag = ib + R;
     int bi[NB], bj[NB];
     bool on[NB];
 #pragma unroll
     for (int n_ = 0; n_ < NB; ++n_) {
-        const int b = n_ * 256 + t;
+        const int b = n_ * TEAM + t;
         on[n_] = b < nblk;
         f64_decode(on[n_] ? b : 0, f4, true, bi[n_], bj[n_]);
     }
-    for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+    for (int64_t row = (int64_t)blockIdx.x * NTEAM + tw; row < n; row += (int64_t)gridDim.x * NTEAM) {
         const int64_t lo = indptr[row], hi = indptr[row + 1];
         if (hi == lo) {                                              // no stored entries: zeros (wmf_model.py:274-276, :296-298)
-            for (int c = t; c < f; c += 256) X[row * f + c] = 0.0;
+            for (int c = t; c < f; c += TEAM) X[row * f + c] = 0.0;
             continue;
         }
         double acc[NB][16];
@@ -168,24 +193,24 @@ __global__ __launch_bounds__(256) void solve64v2_kernel(const double* __restrict
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[n_][i] = 0.0;
         if (t == 0) *flag = 0;
-        // ---- A = sum_e w_e y_e y_e^T, b = sum_e (w_e + 1) y_e over the row's entries, F64_R at a time
-        for (int64_t c0 = lo; c0 < hi; c0 += F64_R) {
-            const int nvalid = (int)min((int64_t)F64_R, hi - c0);
-            __syncthreads();                                         // the previous pass is done with ys / wv
+        // ---- A = sum_e w_e y_e y_e^T, b = sum_e (w_e + 1) y_e over the row's entries, R at a time
+        for (int64_t c0 = lo; c0 < hi; c0 += R) {
+            const int nvalid = (int)min((int64_t)R, hi - c0);
+            f64_team_sync<TEAM>();                                   // the previous pass is done with ys / wv
             if (t < nvalid) {
                 const int idx = indices[c0 + t];
                 const double w = vals[c0 + t] - (bias ? Y[(int64_t)idx * f] : 0.0);   // data - bias[idx], :279
                 ib[t] = idx; wv[t] = w; pv[t] = w + 1.0;
             }
-            __syncthreads();
-            for (int i = t; i < nvalid * FPA; i += 256) {
+            f64_team_sync<TEAM>();
+            for (int i = t; i < nvalid * FPA; i += TEAM) {
                 const int e = i / FPA, c = i - e * FPA;
                 double v = 0.0;
                 if (c < f) v = (bias && c == 0) ? 1.0 : Y[(int64_t)ib[e] * f + c];
                 else if (c == FP) v = pv[e];
                 ys[i] = v;
             }
-            __syncthreads();
+            f64_team_sync<TEAM>();
             f64_accumulate<NB>(acc, bi, bj, on, ys, FPA, wv, nvalid, f4);
         }
         // ---- + G (lambda included); rows / columns of padding get a unit diagonal: their unknowns are zero
@@ -211,15 +236,16 @@ __global__ __launch_bounds__(256) void solve64v2_kernel(const double* __restrict
             for (int n_ = 0; n_ < NB; ++n_) {
                 if (on[n_] && bi[n_] == kb && bj[n_] == kb) {        // (a) the diagonal block: R_kk, then its inverse (upper triangular)
                     double* a = acc[n_];
-                    double r[4][4], iv[4][4];
+                    double r[4][4], iv[4][4], rinv[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         double dgl = a[5 * i];
 #pragma unroll
                         for (int k = 0; k < i; ++k) dgl -= r[k][i] * r[k][i];
-                        if (!(dgl > 0.0)) bad = true;                // not positive definite (or NaN): the LU kernel takes the row
-                        const double rii = sqrt(dgl), inv = 1.0 / rii;
-                        r[i][i] = rii;
+                        if (!(dgl > 0.0) || !(dgl < 1.0e300)) { bad = true; dgl = 1.0; }   // not positive definite (or not finite): the LU kernel takes the row
+                        const double inv = f64_rsqrt(dgl);
+                        rinv[i] = inv;
+                        r[i][i] = dgl * inv;
 #pragma unroll
                         for (int j = i + 1; j < 4; ++j) {
                             double v = a[4 * i + j];
@@ -235,20 +261,20 @@ __global__ __launch_bounds__(256) void solve64v2_kernel(const double* __restrict
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        iv[j][j] = 1.0 / r[j][j];
+                        iv[j][j] = rinv[j];
 #pragma unroll
                         for (int i = j - 1; i >= 0; --i) {
                             double v = 0.0;
 #pragma unroll
                             for (int k = i + 1; k <= j; ++k) v += r[i][k] * iv[k][j];
-                            iv[i][j] = -v / r[i][i];
+                            iv[i][j] = -v * rinv[i];
                         }
                     }
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { a[i] = iv[i >> 2][i & 3]; db[i] = a[i]; }   // the owner keeps R_kk^-1 for the back substitution
                 }
             }
-            __syncthreads();
+            f64_team_sync<TEAM>();
 #pragma unroll
             for (int n_ = 0; n_ < NB; ++n_) {
                 if (on[n_] && bi[n_] == kb && bj[n_] > kb) {         // (b) block row kb: R_kj = R_kk^-T A_kj
@@ -274,7 +300,7 @@ __global__ __launch_bounds__(256) void solve64v2_kernel(const double* __restrict
                     }
                 }
             }
-            __syncthreads();
+            f64_team_sync<TEAM>();
 #pragma unroll
             for (int n_ = 0; n_ < NB; ++n_) {
                 if (on[n_] && bi[n_] > kb) {                         // (c) trailing update A_ij -= R_ki^T R_kj
@@ -295,11 +321,17 @@ __global__ __launch_bounds__(256) void solve64v2_kernel(const double* __restrict
                 }
             }
         }
-        if (bad) *flag = 1;
-        __syncthreads();
-        if (*flag) {                                                 // uniform: hand the row to the pivoted kernel
-            if (t == 0) fb_rows[atomicAdd(fb_count, 1)] = (int32_t)row;
+        bool give_up;
+        if constexpr (TEAM == 256) {
+            if (bad) *flag = 1;
             __syncthreads();
+            give_up = *flag != 0;
+            __syncthreads();                                         // (the flag is cleared again at the top of the next row)
+        } else {
+            give_up = __any(bad);
+        }
+        if (give_up) {                                               // uniform over the team: hand the row to the pivoted kernel
+            if (t == 0) fb_rows[atomicAdd(fb_count, 1)] = (int32_t)row;
             continue;
         }
         // ---- back substitution R x = y, block column by block column; every R block is still in its owner's registers
@@ -319,7 +351,7 @@ __global__ __launch_bounds__(256) void solve64v2_kernel(const double* __restrict
                     }
                 }
             }
-            __syncthreads();
+            f64_team_sync<TEAM>();
 #pragma unroll
             for (int n_ = 0; n_ < NB; ++n_) {
                 if (on[n_] && bj[n_] == kb && bi[n_] < kb) {         // y_bi -= R_(bi, kb) x_kb: one owner per (bi, kb)
@@ -329,7 +361,7 @@ __global__ __launch_bounds__(256) void solve64v2_kernel(const double* __restrict
                         yv[4 * bi[n_] + x] -= u[4 * x] * xs[0] + u[4 * x + 1] * xs[1] + u[4 * x + 2] * xs[2] + u[4 * x + 3] * xs[3];
                 }
             }
-            __syncthreads();
+            f64_team_sync<TEAM>();
         }
     }
 }
@@ -454,27 +486,38 @@ int64_t wmf_f64_ws_bytes(int f, int64_t m, int64_t n) {
 }
 
 template <int NB>
-static void launch_f64_nb(const double* Y, int64_t m, int f, int bias, const int64_t* indptr, const int32_t* indices,
-                          const double* values, int64_t n, double lambda, double* X, double* partial, double* G, int32_t* fb_rows,
-                          int32_t* fb_count, int nwg, hipStream_t st) {
+static void launch_gram64(const double* Y, int64_t m, int f, int bias, double lambda, double* partial, double* G, int nwg, hipStream_t st) {
     const int f4 = (f + 3) / 4, FP = 4 * f4;
-    const size_t lds_g = (size_t)(F64_R * FP + F64_R) * 8, lds_s = solve64v2_lds_bytes(f);
+    const size_t lds_g = (size_t)(F64_R * FP + F64_R) * 8;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gram64v2_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute((const void*)solve64v2_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         attr_set = true;
     }
     static const char* nmg = wmf_kname("gram64v2_kernel<%d>", NB);
-    static const char* nms = wmf_kname("solve64v2_kernel<%d>", NB);
     const int64_t rpb = (m + nwg - 1) / nwg;
     WMF_LAUNCH(nmg, (gram64v2_kernel<NB>), dim3(nwg), dim3(256), lds_g, st, Y, m, f, bias, partial, rpb);
     const int nel = f64_blocks(f, false) * 16;
     WMF_LAUNCH("gram64v2_reduce_kernel", gram64v2_reduce_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, partial, nwg, f,
                lambda, G);
-    if (n > 0)
-        WMF_LAUNCH(nms, (solve64v2_kernel<NB>), dim3(solve64_blocks(n)), dim3(256), lds_s, st, Y, f, bias, G, indptr, indices, values,
-                   n, X, fb_rows, fb_count);
+}
+
+template <int NB, int TEAM, int R>
+static void launch_solve64(const double* Y, int f, int bias, const double* G, const int64_t* indptr, const int32_t* indices,
+                           const double* values, int64_t n, double* X, int32_t* fb_rows, int32_t* fb_count, hipStream_t st) {
+    const int team_doubles = (int)((solve64v2_team_doubles(f, R) + 1) & ~(size_t)1);           // 16-byte aligned slices
+    const size_t lds = (size_t)team_doubles * 8 * (256 / TEAM);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)solve64v2_kernel<NB, TEAM, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    static const char* nms = wmf_kname("solve64v2_kernel<%d, %d, %d>", NB, TEAM, R);
+    const int64_t teams = 256 / TEAM;
+    int64_t grid = (n + teams - 1) / teams;
+    if (grid > 4096) grid = 4096;
+    WMF_LAUNCH(nms, (solve64v2_kernel<NB, TEAM, R>), dim3((unsigned)grid), dim3(256), lds, st, Y, f, bias, G, indptr, indices, values, n,
+               X, fb_rows, fb_count, team_doubles);
 }
 
 int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const int64_t* indptr, const int32_t* indices,
@@ -487,16 +530,28 @@ int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const 
     int32_t* fb_count = reinterpret_cast<int32_t*>(slices + (int64_t)WMF_F64_LU_GRID * (ff + f));
     int32_t* fb_rows = fb_count + 64;
     if (hipMemsetAsync(fb_count, 0, 256, st) != hipSuccess) return -2;
-    // (the Gramian has no right-hand-side column, the row systems do: the block count per thread follows the larger)
-    switch (f64_nb(f64_blocks(f, true))) {
-#define C_(N) case N: launch_f64_nb<N>(Y, m, f, bias, indptr, indices, values, n, lambda, X, partial, G, fb_rows, fb_count, nwg, st); break;
+    switch (f64_nb(f64_blocks(f, false))) {
+#define C_(N) case N: launch_gram64<N>(Y, m, f, bias, lambda, partial, G, nwg, st); break;
         C_(1) C_(2) C_(3) C_(5) C_(9)
 #undef C_
         default: return -1;
     }
-    if (n > 0)                                      // rows the Cholesky kernel could not take (count on the device; none as a rule)
+    if (n > 0) {
+        const int nblk = f64_blocks(f, true);
+#define S_(N, T, R) launch_solve64<N, T, R>(Y, f, bias, G, indptr, indices, values, n, X, fb_rows, fb_count, st)
+        if (nblk <= 64) S_(1, 64, 8);                 // one WAVE per row while a lane holds at most three blocks (f <= 68)
+        else if (nblk <= 128) S_(2, 64, 8);
+        else if (nblk <= 192) S_(3, 64, 8);
+        else if (nblk <= 256) S_(1, 256, 16);         // one workgroup per row beyond
+        else if (nblk <= 512) S_(2, 256, 16);
+        else if (nblk <= 768) S_(3, 256, 16);
+        else if (nblk <= 1280) S_(5, 256, 16);
+        else S_(9, 256, 16);
+#undef S_
+        // rows the Cholesky kernel could not take (count on the device; none as a rule)
         WMF_LAUNCH("solve64_lu_kernel", solve64_lu_kernel, dim3(WMF_F64_LU_GRID), dim3(256), 0, st, Y, f, bias, G, indptr, indices,
                    values, fb_rows, fb_count, X, slices, fail);
+    }
     return 0;
 }
 

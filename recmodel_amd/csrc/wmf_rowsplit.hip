@@ -26,6 +26,10 @@
 
 #include <utility>
 
+#ifndef RS_GJ_LDS
+#define RS_GJ_LDS true   /* multiplier column of the tile inverse by ds_bpermute (true) or by VALU lane swaps (false) */
+#endif
+
 typedef _Float16 rs_f16x8 __attribute__((ext_vector_type(8)));
 // a tile's four values per lane (k = 4q + e) as { h_0..h_3, l_0..l_3 }: the "natural" split-f16 operand of wmf_dw_elim.h
 __device__ __forceinline__ rs_f16x8 rs_split_natural(const f32x4 v) {     // (C++ on purpose: see dw_split_natural, wmf_dw_elim.h)
@@ -421,7 +425,7 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
             constexpr int b0 = rs_base<NFB, W>(S);
             if constexpr (bi < NFB) {
                 f32x4 X = acc[b0];
-                gj_inv_sweep<true, true, true>(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});   // (pivots above WMF_PIVOT_CAP bounce the row)
+                gj_inv_sweep<RS_GJ_LDS, true, true>(X, baddr, r, q, ok, std::make_integer_sequence<int, 16>{});   // (pivots above WMF_PIVOT_CAP bounce the row)
                 float yp = yacc[S];
                 yp = wmf_qsum(yp);
                 float wv0 = X[0] * yp, wv1 = X[1] * yp, wv2 = X[2] * yp, wv3 = X[3] * yp;

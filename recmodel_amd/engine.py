@@ -33,6 +33,17 @@ exchange of one chunk behind the accumulation of the next -- and each rank elimi
 x f; the engine picks the mode per side from exactly that comparison (REDUCE_GAIN), and a side whose only consumer runs
 in reduce mode is not gathered at all until somebody asks for it (get_factors).
 
+Need-list (sparse) gather of the users.  The item half step reads the row of every user that interacted with one of THIS
+rank's items -- with 8 ranks and ~10 items per user that is 1 - (7/8)^10 = 74 % of the users, not all of them, and the
+user block is what fills the xGMI links of a strong-scaling run (10 M x 129 floats: 0.66 GB per link and iteration at 8
+GPUs, twice the time of the row solves).  When the fraction a rank needs is below SPARSE_MAX_FRACTION on every rank, each
+rank therefore receives only those rows: at set-up every rank tells every other which of its local rows it needs (per
+chunk), a chunk of freshly solved rows is packed per destination (index_select) and travels by ONE all_to_all_single with
+split sizes instead of the all-gather, and lands in a COMPACT gathered matrix -- chunk-major, source-major, ascending local
+row: exactly the order of the sorted needed positions, so the item-major CSR is re-indexed once and nothing is scattered
+on arrival; the whitening pass runs over the compact matrix (the same fraction fewer rows).  Items stay dense (every rank
+needs nearly all of them, and the evaluation reads them by id); get_factors gathers a sparse side densely on demand.
+
 Pipelined gather mode.  When the fixed side does arrive by all-gather in several chunks and the rows being updated are
 heavy (cfg2's items at 2 and 4 GPUs: hundreds of entries per row and chunk), the update does not wait for the last
 chunk: the gathered matrix is chunk-major, so a row's entries are grouped by chunk; as soon as chunk c has landed and
@@ -212,6 +223,7 @@ def coo_to_csr(rows, cols, vals, n_rows, kernels=None, n_cols=None):
 MIN_CHUNK_ROWS = 32768          # default chunking never makes chunks smaller than this
 REDUCE_GAIN = 0.8               # reduce mode when its bytes per link are below this fraction of the all-gather's
 PIPE_MIN_ENTRIES = 48           # pipelined gather mode only when a row has at least this many entries per arriving chunk
+SPARSE_MAX_FRACTION = 0.85      # need-list gather of the users when no rank needs more than this fraction of them
 
 
 class Sharding:
@@ -315,7 +327,7 @@ class AlsEngine:
     """Weighted-ALS state of one rank: factor blocks, whitened gathers, CSR shards."""
 
     def __init__(self, n_users, n_items, dim, bias, gamma, device=None, group=None, kernels=None, chunks=None,
-                 reduce_mode=None, pipe_mode=None, force_exchange=None):
+                 reduce_mode=None, pipe_mode=None, force_exchange=None, sparse_mode=None):
         self.K = kernels if kernels is not None else HipKernels()     # raises without a GPU / built library
         self.lib = getattr(self.K, "lib", None)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -338,7 +350,7 @@ class AlsEngine:
         self.f = self.dim + 1 if self.bias else self.dim
         self.ld = self.K.ld_for(self.f)
         self.pr = self.K.partial_row_floats(self.f) if hasattr(self.K, "partial_row_floats") else 0
-        self._reduce_arg, self.pipe_mode, self._chunks_arg = reduce_mode, pipe_mode, chunks
+        self._reduce_arg, self.pipe_mode, self._chunks_arg, self._sparse_arg = reduce_mode, pipe_mode, chunks, sparse_mode
         self.csr = {}          # "users": shard with local user rows, "items": shard with local item rows
         self.csr_chunks = {}   # the same rows as one Csr (own row plan) per chunk
         self._configure({s: Sharding(self.n[s], self.world, self.rank) for s in self.n})
@@ -383,6 +395,12 @@ class AlsEngine:
         self.chunk_bounds = {s: [(lo, min(self.chunk_len[s], self.rpr[s] - lo))
                                  for lo in range(0, max(self.rpr[s], 1), self.chunk_len[s]) if lo < self.rpr[s]]
                              for s in self.n}
+        # rows [start, stop) of chunk c in the GATHERED matrix of a side (dense gather: W x the chunk; a need-list gather
+        # replaces them by the compact ranges, _setup_sparse)
+        self.chunk_range = {s: [(W * lo, W * (lo + ln)) for lo, ln in self.chunk_bounds[s]] for s in self.n}
+        self.sparse = {s: False for s in self.n}
+        self.need = {}
+        self._keep = []                                                        # send buffers of exchanges in flight
         dev, f32 = self.device, torch.float32
         z = lambda *shape, dtype=f32: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
         # local factor blocks [rows_per_rank, ld]; rows >= n_local are padding and stay zero
@@ -543,8 +561,13 @@ class AlsEngine:
         """mine[side] = (row ids, column ids, values) of the entries whose ``side`` row this rank owns."""
         for side in ("users", "items"):
             r_, c_, v_ = mine[side]
-            full = self._shard(side, r_, c_, v_)
-            self.csr[side] = full
+            self.csr[side] = self._shard(side, r_, c_, v_)
+        for side in ("users", "items"):
+            if self.reduce[side]:
+                self.csr_red[side] = self._shard_reduce(side)          # (built on the dense positions of ``side``)
+        self._setup_sparse()                                           # may re-index csr["items"] into a compact gather of the users
+        for side in ("users", "items"):
+            full = self.csr[side]
             bounds = self.chunk_bounds[side]
             if len(bounds) == 1:
                 self.csr_chunks[side] = [full]
@@ -555,10 +578,77 @@ class AlsEngine:
                         full.values[edges[c]: edges[c + 1]], full.n_cols, self.f, self.bias)
                     for c, (lo, ln) in enumerate(bounds)]
         for side in ("users", "items"):
-            if self.reduce[side]:
-                self.csr_red[side] = self._shard_reduce(side)
-            else:
+            if not self.reduce[side]:
                 self._setup_pipe(side)
+
+    def _setup_sparse(self):
+        """Need-list gather of the users (module docstring), decided jointly: every rank must take the same path."""
+        S, consumer = "users", "items"
+        forced = os.environ.get("WMF_SPARSE") if self._sparse_arg is None else ("1" if self._sparse_arg else "0")
+        if not self.exchange or self.reduce[consumer] or forced == "0":
+            return
+        W, dev = self.world, self.device
+        shard = self.csr[consumer]
+        idx = shard.indices.to(torch.int64)
+        P = torch.unique(idx)                                          # needed dense positions, ascending = the compact order
+        total = W * self.rpr[S]
+        frac = torch.tensor([P.numel() / max(1, total)], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(frac, op=torch.distributed.ReduceOp.MAX, group=self.group)
+        if forced != "1" and float(frac.item()) >= SPARSE_MAX_FRACTION:
+            return
+        bounds = self.chunk_bounds[S]
+        starts = torch.tensor([W * lo for lo, _ in bounds], dtype=torch.int64, device=dev)
+        los = torch.tensor([lo for lo, _ in bounds], dtype=torch.int64, device=dev)
+        lns = torch.tensor([ln for _, ln in bounds], dtype=torch.int64, device=dev)
+        c = torch.bucketize(P, starts, right=True) - 1                 # chunk of every needed position
+        rel = P - starts[c]
+        src = rel // lns[c]                                            # the rank that owns the row ...
+        row = los[c] + rel % lns[c]                                    # ... and its local row there
+        C = len(bounds)
+        recv_counts = torch.bincount(c * W + src, minlength=C * W).reshape(C, W)
+        coff = torch.zeros(C + 1, dtype=torch.int64)
+        coff[1:] = torch.cumsum(recv_counts.sum(1).cpu(), 0)
+        # tell every owner which of its rows this rank needs (one exchange at set-up): (requester, chunk, local row)
+        me = torch.full_like(row, self.rank)
+        if W > 1:
+            req, cc, rr = self._exchange(src, (me, c, row))
+        else:
+            req, cc, rr = me, c, row
+        order = torch.argsort(cc * W + req, stable=True)               # chunk-major, requester-major; rows stay ascending
+        req, cc, rr = req[order], cc[order], rr[order]
+        send_counts = torch.bincount(cc * W + req, minlength=C * W).reshape(C, W)
+        soff = torch.zeros(C + 1, dtype=torch.int64)
+        soff[1:] = torch.cumsum(send_counts.sum(1).cpu(), 0)
+        self.need[S] = {
+            "send_idx": [rr[int(soff[k]): int(soff[k + 1])].contiguous() for k in range(C)],
+            "send_counts": [[int(x) for x in send_counts[k].tolist()] for k in range(C)],
+            "recv_counts": [[int(x) for x in recv_counts[k].tolist()] for k in range(C)],
+            "needed_fraction": P.numel() / max(1, total),
+        }
+        shard.indices.copy_(torch.searchsorted(P, idx).to(torch.int32))        # the item-major CSR now points into the compact matrix
+        n_compact = max(1, int(P.numel()))
+        shard.n_cols = n_compact
+        self.sparse[S] = True
+        self.chunk_range[S] = [(int(coff[k]), int(coff[k + 1])) for k in range(C)]
+        f32 = torch.float32
+        self.X[S] = torch.zeros(n_compact, self.ld, dtype=f32, device=dev)
+        self.V[S] = torch.zeros(n_compact, self.ldv, dtype=f32, device=dev)
+        self.bias_vec[S] = torch.zeros(n_compact, 2, dtype=f32, device=dev) if self.split else torch.zeros(n_compact, dtype=f32, device=dev)
+        if self.has_factors[S]:                                        # factors loaded before the interactions: publish them again
+            for k in range(C):
+                self._publish(S, k)
+
+    def exchange_bytes_sent(self, side):
+        """Bytes this rank SENDS to other ranks when its freshly solved block of ``side`` is exchanged once (one half step):
+        the dense all-gather sends the whole block to each of the W - 1 peers, the need-list gather only the rows each peer
+        asked for; 0 when the other side runs in reduce mode (the block then stays where it is)."""
+        if not self.exchange or self.reduce[self._other(side)]:
+            return 0
+        row_bytes = self.ld * 4
+        if self.sparse[side]:
+            sc = self.need[side]["send_counts"]
+            return sum(n for per_chunk in sc for d, n in enumerate(per_chunk) if d != self.rank) * row_bytes
+        return (self.world - 1) * self.rpr[side] * row_bytes
 
     def _setup_pipe(self, side):
         """Pipelined gather mode for ``side`` (module docstring) if its rows are heavy enough per arriving chunk."""
@@ -575,8 +665,8 @@ class AlsEngine:
         idx = full.indices.to(torch.int64)
         rows = torch.repeat_interleave(torch.arange(n, device=self.device), full.indptr[1:] - full.indptr[:-1])
         subs = []
-        for lo, ln in bounds:
-            m = (idx >= W * lo) & (idx < W * (lo + ln))
+        for start, stop in self.chunk_range[fixed]:
+            m = (idx >= start) & (idx < stop)
             cnt = torch.bincount(rows[m], minlength=n)
             ptr = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
             torch.cumsum(cnt, 0, out=ptr[1:])
@@ -618,8 +708,16 @@ class AlsEngine:
 
     def get_factors(self, side):
         """Full [n, f] factor matrix on the host, in id order."""
-        self._ensure_gathered(side)
         ids = torch.arange(self.n[side], device=self.device)
+        if self.sparse[side]:                        # the compact matrix holds only what this rank's items need: gather densely, once
+            W = self.world
+            self._wait(side)
+            dense = torch.zeros(W * self.rpr[side], self.ld, dtype=torch.float32, device=self.device)
+            for lo, ln in self.chunk_bounds[side]:
+                torch.distributed.all_gather_into_tensor(dense[W * lo: W * (lo + ln)], self.factors[side][lo: lo + ln].contiguous(),
+                                                         group=self.group)
+            return dense[self.positions(side, ids)][:, : self.f].cpu().numpy()
+        self._ensure_gathered(side)
         return self.X[side][self.positions(side, ids)][:, : self.f].cpu().numpy()
 
     # ---------------------------------------------------------------- exchange
@@ -633,8 +731,43 @@ class AlsEngine:
             return
         lo, ln = self.chunk_bounds[side][c]
         W = self.world
+        if self.sparse[side]:
+            need = self.need[side]
+            start, stop = self.chunk_range[side][c]
+            send = self.factors[side].index_select(0, need["send_idx"][c])          # packed per destination, rows ascending
+            self._pending[side].append(self._all_to_all_rows(self.X[side][start:stop], send, need["recv_counts"][c],
+                                                             need["send_counts"][c]))
+            return
         self._pending[side].append(torch.distributed.all_gather_into_tensor(
             self.X[side][W * lo: W * (lo + ln)], self.factors[side][lo: lo + ln], group=self.group, async_op=True))
+
+    def _all_to_all_rows(self, out, send, recv_counts, send_counts):
+        """out = the rows every rank packed for this one (source-major), send = this rank's rows packed per destination.
+        RCCL: one asynchronous all_to_all_single with split sizes.  gloo (CPU rehearsal): every rank all-gathers the padded
+        send buffers and keeps its part.  Returns something with .wait() (or None)."""
+        W = self.world
+        if torch.distributed.get_backend(self.group) == "nccl":
+            work = torch.distributed.all_to_all_single(out, send, list(recv_counts), list(send_counts), group=self.group, async_op=True)
+            self._keep.append(send)                  # the send buffer must outlive the call
+            return work
+        cap = torch.tensor([send.shape[0]], dtype=torch.int64)
+        torch.distributed.all_reduce(cap, op=torch.distributed.ReduceOp.MAX, group=self.group)
+        pad = torch.zeros(int(cap.item()), send.shape[1], dtype=send.dtype, device=send.device)
+        pad[: send.shape[0]] = send
+        gathered = [torch.empty_like(pad) for _ in range(W)]
+        torch.distributed.all_gather(gathered, pad, group=self.group)
+        counts = torch.tensor(send_counts, dtype=torch.int64)
+        all_counts = [torch.empty_like(counts) for _ in range(W)]
+        torch.distributed.all_gather(all_counts, counts, group=self.group)
+        at = 0
+        for srcr in range(W):
+            cnts = all_counts[srcr]
+            lo = int(cnts[: self.rank].sum())
+            n = int(cnts[self.rank])
+            assert n == recv_counts[srcr]
+            out[at: at + n] = gathered[srcr][lo: lo + n]
+            at += n
+        return None
 
     def _ensure_gathered(self, side):
         """X[side] complete on this rank (reduce mode leaves it un-gathered until somebody needs it)."""
@@ -647,8 +780,11 @@ class AlsEngine:
     def _wait(self, side):
         """Make the current stream wait for every all-gather of ``side`` still in flight."""
         for work in self._pending[side]:
-            work.wait()
+            if work is not None:
+                work.wait()
         self._pending[side] = []
+        if not any(self._pending.values()):
+            self._keep = []
 
     # ---------------------------------------------------------------- one half step
     def prepare(self, fixed):
@@ -671,13 +807,13 @@ class AlsEngine:
             self._ensure_gathered(fixed)                             # it was last updated while nobody needed all of it
         pending, self._pending[fixed] = self._pending[fixed], []
         done = len(self.chunk_bounds[fixed]) - len(pending)          # chunks whose gather was waited for earlier
-        W = self.world
-        for c, (lo, ln) in enumerate(self.chunk_bounds[fixed]):
-            if c >= done:
+        for c, (start, stop) in enumerate(self.chunk_range[fixed]):
+            if c >= done and pending[c - done] is not None:
                 pending[c - done].wait()
-            rows = slice(W * lo, W * (lo + ln))
-            K.row_transform(self.X[fixed][rows], W * ln, self.f, self.ld, self.W_white, self.bias, V[rows],
-                            bvec[rows] if self.bias else None)
+            rows = slice(start, stop)
+            if stop > start:
+                K.row_transform(self.X[fixed][rows], stop - start, self.f, self.ld, self.W_white, self.bias, V[rows],
+                                bvec[rows] if self.bias else None)
 
     def update(self, side):
         """Solve every local row of ``side`` against the prepared fixed side.  wmf_model.py:220-239."""
@@ -717,12 +853,13 @@ class AlsEngine:
         V, bvec = self.V[fixed], self.bias_vec[fixed]
         self._wait(side)
         n, C = self.rpr[side], len(bounds)
-        for c, ((lo, ln), (ptr, deg, idx, val, w_eff)) in enumerate(zip(bounds, self.csr_pipe[side])):
-            if c >= done:
+        for c, ((start, stop), (ptr, deg, idx, val, w_eff)) in enumerate(zip(self.chunk_range[fixed], self.csr_pipe[side])):
+            if c >= done and pending[c - done] is not None:
                 pending[c - done].wait()
-            rows = slice(W * lo, W * (lo + ln))
-            K.row_transform(self.X[fixed][rows], W * ln, self.f, self.ld, self.W_white, self.bias, V[rows],
-                            bvec[rows] if self.bias else None)
+            rows = slice(start, stop)
+            if stop > start:
+                K.row_transform(self.X[fixed][rows], stop - start, self.f, self.ld, self.W_white, self.bias, V[rows],
+                                bvec[rows] if self.bias else None)
             K.accumulate_rows(V, bvec if self.bias else None, ptr, deg, idx, val, n, idx.numel(), self.f, self.ld,
                               self.partial_pipe[side], w_eff, slot_stride=C, slot_offset=c)
         before = self._fail_snapshot()
@@ -799,7 +936,7 @@ class AlsEngine:
         K, W = self.K, self.world
         fixed = self._other(side)
         self._ensure_gathered(fixed)
-        K.row_transform(self.X[fixed], W * self.rpr[fixed], self.f, self.ld, self.W_white, self.bias, self.V[fixed],
+        K.row_transform(self.X[fixed], self.X[fixed].shape[0], self.f, self.ld, self.W_white, self.bias, self.V[fixed],
                         self.bias_vec[fixed] if self.bias else None)
         self.update(side)
 

@@ -333,3 +333,94 @@ def test_bias_model_in_reduce_and_pipe_mode_survives_negative_weights(tmp_path, 
     items = orc.recompute_factors_bias(users, C.T.tocsr(), 0.1)
     np.testing.assert_allclose(got["users"], users, rtol=5e-4, atol=5e-5)
     np.testing.assert_allclose(got["items"], items, rtol=5e-4, atol=5e-5)
+
+
+# ------------------------------------------------------------------ need-list (sparse) gather of the users
+def _sparse_matrix(n_users, n_items):
+    """Users with 1 .. 3 items each, most of them inside one eighth of the catalogue: with items dealt over 4 or 8 ranks a
+    rank's items are touched by a fraction of the users only."""
+    from recmodel_amd import synth
+    indptr, indices, counts = synth.make_counts(n_users, n_items, 2, seed=21)
+    return indptr, indices, counts
+
+
+def _worker_sparse(rank, world, port, bias, out_path, mode, distributed):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_kernels import NumpyKernels
+        from oracle import wmf_oracle as orc
+        from recmodel_amd.engine import AlsEngine
+        n_users, n_items, dim = 331, 96, 5
+        indptr, indices, counts = _sparse_matrix(n_users, n_items)
+        values = (10 * torch.log(1 + counts)).to(torch.float32)
+        kw = {"gather": {"pipe_mode": False}, "pipe": {"pipe_mode": True}}[mode]
+        eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cpu", kernels=NumpyKernels(), chunks=3, reduce_mode=False, **kw)
+        if distributed:
+            per = n_users // world
+            lo = rank * per
+            hi = n_users if rank == world - 1 else lo + per
+            e0, e1 = int(indptr[lo]), int(indptr[hi])
+            eng.set_interactions_distributed(lo, indptr[lo: hi + 1] - e0, indices[e0:e1], values[e0:e1], balance=True)
+        else:
+            eng.set_interactions(indptr, indices, values)
+        assert eng.sparse == {"users": True, "items": False}, eng.sparse
+        # what this rank must send, recomputed from the matrix alone: a user row goes to every OTHER rank that owns one of the
+        # user's items -- and nothing else travels
+        sh_u, sh_i = eng.shard["users"], eng.shard["items"]
+        rows = torch.repeat_interleave(torch.arange(n_users), indptr[1:] - indptr[:-1])
+        owner_u, owner_i = sh_u.owner_of(rows), sh_i.owner_of(indices.to(torch.int64))
+        pairs = torch.unique(torch.stack([rows[owner_u == rank], owner_i[owner_u == rank]], 1), dim=0)     # (my user, rank that needs it)
+        want_rows = int((pairs[:, 1] != rank).sum())
+        sent = eng.exchange_bytes_sent("users")
+        assert sent == want_rows * eng.ld * 4, (sent, want_rows)
+        dense = (world - 1) * eng.rpr["users"] * eng.ld * 4
+        assert eng.exchange_bytes_sent("items") == (world - 1) * eng.rpr["items"] * eng.ld * 4
+        eng.set_factors("items", orc.init_items(n_items, dim, bias))
+        for _ in range(2):
+            eng.half_step("users")
+            eng.half_step("items")
+        eng.check_numerics()
+        shard = eng.make_eval_shard(indptr, indices, counts)
+        sq, ab, cnt = eng.eval_sums(shard)
+        users, items = eng.get_factors("users"), eng.get_factors("items")
+        tot = torch.tensor([float(sent), float(dense)], dtype=torch.float64)
+        dist.all_reduce(tot)
+        if rank == 0:
+            np.savez(out_path, users=users, items=items, sums=np.array([sq, ab, cnt]), bytes=tot.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bias,mode,distributed", [(4, False, "gather", False), (8, True, "gather", False), (4, True, "pipe", False),
+                                                         (8, False, "pipe", True), (4, False, "gather", True)])
+def test_need_list_gather_of_the_users(tmp_path, world, bias, mode, distributed):
+    """SURVEY.md 8(e) / north star: users shard over the ranks, and the item half step needs the rows of the users that touched
+    this rank's items -- a fraction of them.  With the need-list gather every rank sends a solved user row only to the ranks
+    that asked for it (one all_to_all per chunk into a compact gathered matrix the item-major CSR is re-indexed to); the
+    bytes each rank sends are exactly those rows (recomputed from the matrix in the worker), well below the all-gather's,
+    and two ALS iterations equal the single-process oracle -- plain and pipelined gather, round-robin and cost-balanced deal."""
+    from oracle import wmf_oracle as orc
+    from recmodel_amd import synth
+    out = str(tmp_path / "out.npz")
+    mp.spawn(_worker_sparse, args=(world, _free_port(), bias, out, mode, distributed), nprocs=world, join=True)
+    got = np.load(out)
+    n_users, n_items, dim = 331, 96, 5
+    indptr, indices, counts = _sparse_matrix(n_users, n_items)
+    raw = synth.to_scipy(indptr, indices, counts, (n_users, n_items))
+    C = raw.astype(np.float64)
+    C.data = 10 * np.log(1 + C.data)
+    CT = C.T.tocsr()
+    items = orc.init_items(n_items, dim, bias)
+    step = orc.recompute_factors_bias if bias else orc.recompute_factors
+    for _ in range(2):
+        users = step(items, C, 0.1)
+        items = step(users, CT, 0.1)
+    np.testing.assert_allclose(got["users"], users, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(got["items"], items, rtol=2e-4, atol=2e-5)
+    mse = orc.eval_prec(users, items, raw, bias)
+    assert abs(got["sums"][0] / got["sums"][2] - mse) <= 1e-4 * mse and got["sums"][2] == raw.nnz
+    sent, dense = got["bytes"]
+    assert sent < 0.5 * dense, (sent, dense)              # ~2 items per user: a user row travels to ~1.6 of the W - 1 other ranks
