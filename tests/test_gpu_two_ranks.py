@@ -26,7 +26,7 @@ def _free_port():
 SMALL = (1203, 257, 24, 9)          # users, items, k, mean user degree
 
 
-def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None, backend="gloo", shape=SMALL):
+def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None, backend="gloo", shape=SMALL, sparse_mode=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
@@ -42,13 +42,14 @@ def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None,
         indptr, indices, counts = synth.make_counts(n_users, n_items, dbar, seed=11)
         values = (10 * torch.log(1 + counts)).to(torch.float32)
         eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cuda:0", chunks=3, reduce_mode=reduce_mode, pipe_mode=pipe_mode,
-                        force_exchange=True)
+                        force_exchange=True, sparse_mode=sparse_mode)
         assert eng.exchange and len(eng.chunk_bounds["users"]) == 3
         partial_ok = eng.pr > 0                       # partial systems exist for f <= 144 only: wider models always gather
         assert eng.reduce["items"] == (bool(reduce_mode) and partial_ok)
         eng_pipe_expected = bool(pipe_mode) and partial_ok
         eng.set_interactions(indptr, indices, values)
         assert eng.pipe["items"] == eng_pipe_expected and eng.pipe["users"] == eng_pipe_expected
+        assert eng.sparse["users"] == bool(sparse_mode) and not eng.sparse["items"]
         eng.set_factors("items", orc.init_items(n_items, dim, bias))
         for _ in range(2):
             eng.half_step("users")
@@ -107,6 +108,24 @@ def test_one_rank_over_rccl_matches_oracle(tmp_path, bias, reduce_mode, pipe_mod
     out = str(tmp_path / "out.npz")
     mp.spawn(_worker, args=(1, _free_port(), bias, out, reduce_mode, pipe_mode, "nccl"), nprocs=1, join=True)
     _check_against_oracle(np.load(out), bias)
+
+
+@pytest.mark.parametrize("backend,world,k,bias,pipe_mode", [("gloo", 2, 24, False, False), ("gloo", 2, 128, True, False), ("gloo", 2, 128, True, True),
+                                                            ("gloo", 2, 256, False, False), ("nccl", 1, 24, True, False), ("nccl", 1, 64, False, True)])
+def test_need_list_gather_on_the_device(tmp_path, backend, world, k, bias, pipe_mode):
+    """The need-list gather of the users (engine.AlsEngine._setup_sparse) under the real kernels: the item-major CSR re-indexed
+    into the compact gathered matrix, the whitening pass over compact chunk ranges, the row kernels gathering from it -- two
+    ranks on one GPU (gloo transport) at k = 24, 128 + biases (split layout, also pipelined) and 256, and one rank over real
+    RCCL (all_to_all_single with split sizes, asynchronous, ordered by work.wait())."""
+    shape = (1203, 257, k, 9 if k < 100 else 40)
+    out = str(tmp_path / "out.npz")
+    try:
+        mp.spawn(_worker, args=(world, _free_port(), bias, out, False, pipe_mode, backend, shape, True), nprocs=world, join=True)
+    except Exception as exc:
+        if "gloo" in str(exc).lower() and "cuda" in str(exc).lower():
+            pytest.skip(f"gloo cannot move device tensors here: {exc}")
+        raise
+    _check_against_oracle(np.load(out), bias, shape)
 
 
 @pytest.mark.parametrize("k,bias,mode", [(128, True, "gather"), (128, True, "reduce"), (128, True, "pipe"), (128, False, "pipe"),
