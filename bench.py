@@ -335,7 +335,7 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu, zipf=
                    "n_users": n_users, "n_items": n_items, "nnz": nnz, "k": k, "bias": bias,
                    "sharding": f"users+items dealt by cost (nnz f^2 + f^3) over {world} GPU(s), every rank loads 1/{world} of the user "
                                f"rows; exchange users: "
-                               f"{'reduce-scatter of partial systems' if eng.reduce['users'] else 'all-gather'} in "
+                               f"{'reduce-scatter of partial systems' if eng.reduce['users'] else ('need-list all-to-all (%.0f %% of the rows per rank)' % (100 * eng.need['users']['needed_fraction']) if eng.sparse['users'] else 'all-gather')} in "
                                f"{len(eng.chunk_bounds['users'])} chunk(s), items: "
                                f"{'reduce-scatter of partial systems' if eng.reduce['items'] else 'all-gather'} in "
                                f"{len(eng.chunk_bounds['items'])} chunk(s); accumulation pipelined over arriving chunks: "
@@ -349,7 +349,8 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu, zipf=
         "setup_s": t_setup,
         "ranks": {"world_size": (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
                   "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
-                  "nnz_of_the_user_shard_per_rank": per_rank_nnz},
+                  "nnz_of_the_user_shard_per_rank": per_rank_nnz,
+                  "bytes_this_rank_sends_per_half_step": {s_: eng.exchange_bytes_sent(s_) for s_ in SIDES}},
         "row_bins": {s: {"rows": eng.csr[s].bin_rows.tolist(), "nnz": eng.csr[s].bin_nnz.tolist(),
                          "rows_le8": eng.csr[s].rows8, "rows_split": eng.csr[s].rows_split} for s in SIDES},
     }
