@@ -233,7 +233,10 @@ __device__ __forceinline__ void gj_inv_step(f32x4& a, float& dsc, const int (&ba
     const float akr = a[kr];     // copy first: __builtin_bit_cast applied to the vector-element lvalue itself reads element 0
     const float piv = rlw(akr, K + 16 * kq);
     if constexpr (CHECK) { if (!(piv > 1e-20f)) ok = false; }
-    if constexpr (CAP) { plo = fminf(plo, piv); phi = fmaxf(phi, piv); }       // (wave-uniform values: scalar arithmetic)
+    // (wave-uniform values: scalar arithmetic.  A pivot of exactly one belongs to a padding column -- f not a multiple of 16 -- or
+    // to a feature none of the row's entries touches: an identity row and column, decoupled from the rest of the tile, which
+    // says nothing about the conditioning of what it is decoupled from)
+    if constexpr (CAP) { if (piv != 1.f) plo = fminf(plo, piv); phi = fmaxf(phi, piv); }
     const float inv = __builtin_amdgcn_rcpf(piv);
     float fk;
     if constexpr (LDS) fk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(baddr[kq], __builtin_bit_cast(int, akr)));
@@ -270,8 +273,11 @@ __device__ __forceinline__ void gj_inv_step_lean(f32x4& a, float& dsc, int& pmin
     // pivot tests on the scalar unit: the smallest and the largest pivot BIT PATTERN as signed integers -- for positive floats
     // the integer order is the float order, a negative pivot is a negative integer -- which the caller compares with those of
     // 1e-20f (WMF_PIVOT_MIN_BITS) and of WMF_PIVOT_CAP once.  A NaN passes, and reaches the solution, which the caller tests.
-    pmin = min(pmin, __builtin_bit_cast(int, piv));
-    pmax = max(pmax, __builtin_bit_cast(int, piv));
+    // (a pivot of exactly one -- padding column, untouched feature: an identity row and column -- is left out of the minimum:
+    // it is positive, and decoupled from the tile whose conditioning the spread stands for)
+    const int pbits = __builtin_bit_cast(int, piv);
+    pmin = pbits == 0x3f800000 ? pmin : min(pmin, pbits);
+    pmax = max(pmax, pbits);
     const float inv = __builtin_amdgcn_rcpf(piv);
     float fk;
     if constexpr (BP) asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)" : "=v"(fk) : "v"(r4), "v"(akr), "n"(64 * kq));

@@ -4,14 +4,12 @@
 // stored order -- the reference sums them implicitly because every stored entry is one term of the row's normal
 // equations -- and the result does not depend on launch geometry.
 //   keys_kernel      key = row * n_cols + col (64 bit), id = entry number
-//   rocprim::radix_sort_pairs over the significant bits of the key only (stable LSD sort; the one library primitive
-//                    of this file, as in wmf_rank.hip)
+//   wmf_sort_u64     this library's own stable LSD radix sort (wmf_sort.hip), over the significant bits of the key only
 //   gather_kernel    indices[e] = col of the e-th sorted entry (int32), values[e] = its value
 //   indptr_kernel    row pointer from the sorted keys by boundary detection: entry e writes indptr[r] = e for every row r
 //                    in (row of entry e - 1, row of entry e]; no histogram, no scan, no atomics
 #include "wmf_internal.h"
-#include <cstring>            // rocprim/iterator/texture_cache_iterator.hpp uses memset without including it
-#include <rocprim/rocprim.hpp>
+#include "wmf_sort.h"
 
 __global__ __launch_bounds__(256) void csr_keys_kernel(const int64_t* __restrict__ rows, const int64_t* __restrict__ cols,
                                                        int64_t nnz, int64_t n_rows, int64_t n_cols,
@@ -53,22 +51,15 @@ static int key_bits(int64_t n_rows, int64_t n_cols) {
     return b;
 }
 
-static size_t csr_sort_temp_bytes(int64_t nnz, int bits) {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr,
-                                    (uint32_t*)nullptr, (size_t)nnz, 0, bits, (hipStream_t)0);
-    return bytes;
-}
-
 static size_t al256(size_t b) { return (b + 255) / 256 * 256; }
 
-// workspace: [keys nnz x 8][sorted keys][ids nnz x 4][sorted ids][flag 256][rocPRIM temporary]
+// workspace: [keys nnz x 8][sorted keys][ids nnz x 4][sorted ids][flag 256][histograms of the sort]
 int64_t wmf_csr_ws_bytes(int64_t nnz, int64_t n_rows, int64_t n_cols) {
     if (nnz <= 0) return 256;
-    return (int64_t)(2 * al256((size_t)nnz * 8) + 2 * al256((size_t)nnz * 4) + 256 + csr_sort_temp_bytes(nnz, key_bits(n_rows, n_cols)) + 256);
+    return (int64_t)(2 * al256((size_t)nnz * 8) + 2 * al256((size_t)nnz * 4) + 256 + wmf_sort_ws_bytes(nnz) + 256);
 }
 
-// returns 0, -2 (HIP / rocPRIM failure), -3 (workspace too small), -4 (n_rows * n_cols does not fit 63 bits or nnz >= 2^32)
+// returns 0, -2 (HIP failure), -3 (workspace too small), -4 (n_rows * n_cols does not fit 63 bits or nnz >= 2^32)
 int wmf_launch_coo_to_csr(const int64_t* rows, const int64_t* cols, const float* vals, int64_t nnz, int64_t n_rows, int64_t n_cols,
                           int64_t* indptr, int32_t* indices, float* values, int32_t* bad_flag, void* ws, int64_t ws_bytes,
                           hipStream_t st) {
@@ -84,15 +75,13 @@ int wmf_launch_coo_to_csr(const int64_t* rows, const int64_t* cols, const float*
     auto* sids = reinterpret_cast<uint32_t*>(base + 2 * a8 + a4);
     void* temp = base + 2 * a8 + 2 * a4 + 256;
     const int bits = key_bits(n_rows, n_cols);
-    size_t temp_bytes = csr_sort_temp_bytes(nnz, bits);
     int64_t grid = (nnz + 255) / 256;
     if (grid > 16384) grid = 16384;
     WMF_LAUNCH("csr_keys_kernel", csr_keys_kernel, dim3((unsigned)grid), dim3(256), 0, st, rows, cols, nnz, n_rows, n_cols, keys, ids,
                bad_flag);
-    {
-        WmfProfScope ps("rocprim::radix_sort_pairs (coo_to_csr)", st);
-        if (rocprim::radix_sort_pairs(temp, temp_bytes, keys, skeys, ids, sids, (size_t)nnz, 0, bits, st) != hipSuccess) return -2;
-    }
+    bool in_alt = false;
+    if (wmf_sort_u64(keys, skeys, ids, sids, nnz, bits, temp, st, &in_alt)) return -2;
+    if (!in_alt) { auto* tk = keys; keys = skeys; skeys = tk; auto* ti = ids; ids = sids; sids = ti; }   // (skeys / sids: the sorted arrays)
     WMF_LAUNCH("csr_gather_kernel", csr_gather_kernel, dim3((unsigned)grid), dim3(256), 0, st, skeys, sids, vals, nnz, n_cols, indices,
                values);
     WMF_LAUNCH("csr_indptr_kernel", csr_indptr_kernel, dim3((unsigned)grid), dim3(256), 0, st, skeys, nnz, n_rows, n_cols, indptr);

@@ -154,8 +154,11 @@ __device__ __forceinline__ double f64_rsqrt(double x) {
     }
     return y;
 }
+#ifndef F64_WAVE_TEAM_OCC
+#define F64_WAVE_TEAM_OCC 3      /* workgroups per CU the wave-team variants are compiled for (168 registers) */
+#endif
 template <int NB, int TEAM, int R>
-__global__ __launch_bounds__(256) void solve64v2_kernel(const double* __restrict__ Y, int f, int bias, const double* __restrict__ G,
+__global__ __launch_bounds__(256, TEAM == 64 ? F64_WAVE_TEAM_OCC : 1) void solve64v2_kernel(const double* __restrict__ Y, int f, int bias, const double* __restrict__ G,
                                                         const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                         const double* __restrict__ vals, int64_t n, double* __restrict__ X,
                                                         int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int team_doubles) {
@@ -539,7 +542,9 @@ int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const 
     if (n > 0) {
         const int nblk = f64_blocks(f, true);
 #define S_(N, T, R) launch_solve64<N, T, R>(Y, f, bias, G, indptr, indices, values, n, X, fb_rows, fb_count, st)
-        if (nblk <= 64) S_(1, 64, 8);                 // one WAVE per row while a lane holds at most three blocks (f <= 68)
+        const bool waves = !(wmf_debug_flags & 67108864);       // debug flag 67108864 (timing experiments): workgroup teams at every width
+        if (!waves && nblk <= 256) S_(1, 256, 16);
+        else if (nblk <= 64) S_(1, 64, 8);            // one WAVE per row while a lane holds at most three blocks (f <= 68)
         else if (nblk <= 128) S_(2, 64, 8);
         else if (nblk <= 192) S_(3, 64, 8);
         else if (nblk <= 256) S_(1, 256, 16);         // one workgroup per row beyond

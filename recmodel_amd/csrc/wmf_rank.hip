@@ -7,11 +7,10 @@
 //                     The random draws stay on the host, in the reference's np.random call order.
 //   * rank         -- WMF.rank (RecModel/wmf_model.py:25-47): scores of one user against a candidate list (the same
 //                     predict kernel as eval_prec), then a top-n SELECT -- histogram, threshold bin, compaction -- and a
-//                     sort of the short list that survives it (rocPRIM's device sort, on a few thousandths of the
+//                     sort of the short list that survives it (wmf_sort_u64, on a few thousandths of the
 //                     candidates); the batched form (many users) sorts its score matrix by segments.
-#include <cstring>            // rocprim/iterator/texture_cache_iterator.hpp uses memset without including it
 
-#include <rocprim/rocprim.hpp>
+#include "wmf_sort.h"
 
 #include "wmf_common.h"
 #include "wmf_internal.h"
@@ -92,35 +91,36 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float* __restrict
     }
 }
 
-__global__ void batch_index_kernel(int32_t* __restrict__ pos, int32_t* __restrict__ offsets, int64_t nu, int64_t nc) {
+// 64-bit sort keys of the batch: (user slot << 32) | ~rank_key(score): ascending order = users in order, each user's candidates by
+// descending score; the stable sort keeps equal scores in candidate order.  Payload = the candidate's position.
+__device__ __forceinline__ uint32_t rank_key(float s);
+__global__ void batch_keys_kernel(const float* __restrict__ scores, unsigned long long* __restrict__ keys, uint32_t* __restrict__ pos,
+                                  int64_t nu, int64_t nc) {
     const int64_t n = nu * nc;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) pos[i] = (int32_t)(i % nc);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nu; i += (int64_t)gridDim.x * blockDim.x) offsets[i] = (int32_t)(i * nc);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        keys[i] = ((unsigned long long)(i / nc) << 32) | (unsigned long long)(~rank_key(scores[i]));
+        pos[i] = (uint32_t)(i % nc);
+    }
 }
 
-__global__ void take_top_kernel(const int32_t* __restrict__ spos, const float* __restrict__ sscore, int64_t nu, int64_t nc,
+__global__ void take_top_kernel(const uint32_t* __restrict__ spos, const unsigned long long* __restrict__ skeys, int64_t nu, int64_t nc,
                                 int64_t topn, int32_t* __restrict__ out_pos, float* __restrict__ out_scores) {
     const int64_t n = nu * topn;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t u = i / topn, k = i % topn;
-        out_pos[i] = spos[u * nc + k];
-        if (out_scores) out_scores[i] = sscore[u * nc + k];
+        out_pos[i] = (int32_t)spos[u * nc + k];
+        if (out_scores) {
+            const uint32_t key = ~(uint32_t)(skeys[u * nc + k] & 0xFFFFFFFFull);           // rank_key of the score, undone
+            out_scores[i] = __builtin_bit_cast(float, (key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
+        }
     }
 }
 
-static size_t batch_sort_temp_bytes(int64_t nu, int64_t nc) {
-    size_t bytes = 0;
-    (void)rocprim::segmented_radix_sort_pairs_desc(nullptr, bytes, (float*)nullptr, (float*)nullptr, (int32_t*)nullptr,
-                                                   (int32_t*)nullptr, (unsigned)(nu * nc), (unsigned)nu, (int32_t*)nullptr,
-                                                   (int32_t*)nullptr, 0, 32, (hipStream_t)0);
-    return bytes;
-}
-
-// workspace: [scores nu*nc][sorted scores][positions][sorted positions][offsets nu+1][rocPRIM temporary]
+// workspace: [scores nu*nc x 4][keys x 8][sorted keys x 8][positions x 4][sorted positions x 4][histograms of the sort]
 int64_t wmf_rank_batch_ws_bytes(int64_t nu, int64_t nc) {
     if (nu <= 0 || nc <= 0) return 256;
-    const size_t arr = (((size_t)nu * nc * 4 + 255) / 256) * 256, off = (((size_t)(nu + 1) * 4 + 255) / 256) * 256;
-    return (int64_t)(4 * arr + off + batch_sort_temp_bytes(nu, nc) + 256);
+    const size_t arr = (((size_t)nu * nc * 4 + 255) / 256) * 256;
+    return (int64_t)(7 * arr + wmf_sort_ws_bytes(nu * nc) + 256);
 }
 
 int wmf_launch_rank_batch(const float* users, const float* items, int f, int ld, int bias, const int32_t* user_idx, int64_t nu,
@@ -130,15 +130,14 @@ int wmf_launch_rank_batch(const float* users, const float* items, int f, int ld,
     if (nu <= 0 || nc <= 0) return 0;
     if (nu * nc >= (int64_t)1 << 31) return -4;
     if (ws_bytes < wmf_rank_batch_ws_bytes(nu, nc)) return -3;
-    const size_t arr = (((size_t)nu * nc * 4 + 255) / 256) * 256, off = (((size_t)(nu + 1) * 4 + 255) / 256) * 256;
+    const size_t arr = (((size_t)nu * nc * 4 + 255) / 256) * 256;
     char* base = static_cast<char*>(ws);
     float* scores = reinterpret_cast<float*>(base);
-    float* sorted = reinterpret_cast<float*>(base + arr);
-    int32_t* pos = reinterpret_cast<int32_t*>(base + 2 * arr);
-    int32_t* spos = reinterpret_cast<int32_t*>(base + 3 * arr);
-    int32_t* offsets = reinterpret_cast<int32_t*>(base + 4 * arr);
-    void* temp = base + 4 * arr + off;
-    size_t temp_bytes = batch_sort_temp_bytes(nu, nc);
+    auto* keys = reinterpret_cast<unsigned long long*>(base + arr);
+    auto* skeys = reinterpret_cast<unsigned long long*>(base + 3 * arr);
+    uint32_t* pos = reinterpret_cast<uint32_t*>(base + 5 * arr);
+    uint32_t* spos = reinterpret_cast<uint32_t*>(base + 6 * arr);
+    void* temp = base + 7 * arr;
     const int64_t tiles = ((nu + 15) / 16) * ((nc + 15) / 16);
     int64_t grid = (tiles + 3) / 4;
     if (grid > 16384) grid = 16384;
@@ -147,10 +146,13 @@ int wmf_launch_rank_batch(const float* users, const float* items, int f, int ld,
         hipLaunchKernelGGL(score_tile_kernel, dim3((unsigned)grid), dim3(256), 0, st, users, items, ld, bias, user_idx, nu, cand, nc,
                            scores);
     }
-    hipLaunchKernelGGL(batch_index_kernel, dim3(2048), dim3(256), 0, st, pos, offsets, nu, nc);
-    if (rocprim::segmented_radix_sort_pairs_desc(temp, temp_bytes, scores, sorted, pos, spos, (unsigned)(nu * nc), (unsigned)nu,
-                                                 offsets, offsets + 1, 0, 32, st) != hipSuccess) return -2;
-    hipLaunchKernelGGL(take_top_kernel, dim3(1024), dim3(256), 0, st, spos, sorted, nu, nc, topn, out_pos, out_scores);
+    hipLaunchKernelGGL(batch_keys_kernel, dim3(2048), dim3(256), 0, st, scores, keys, pos, nu, nc);
+    int ubits = 1;
+    while ((nu >> ubits) != 0) ++ubits;
+    bool in_alt = false;
+    if (wmf_sort_u64(keys, skeys, pos, spos, nu * nc, 32 + ubits, temp, st, &in_alt)) return -2;
+    hipLaunchKernelGGL(take_top_kernel, dim3(1024), dim3(256), 0, st, in_alt ? spos : pos, in_alt ? skeys : keys, nu, nc, topn, out_pos,
+                       out_scores);
     return 0;
 }
 
@@ -215,31 +217,25 @@ __global__ __launch_bounds__(256) void rank_compact_kernel(const float* __restri
     const uint32_t T = ctrl[0];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const uint32_t k = rank_key(scores[i]);
-        if ((k >> 20) >= T) keys[atomicAdd(&ctrl[1], 1u)] = ((unsigned long long)k << 32) | (0xFFFFFFFFu - (uint32_t)i);
+        // (~k, i): ascending order of these keys = descending score, equal scores in candidate order
+        if ((k >> 20) >= T) keys[atomicAdd(&ctrl[1], 1u)] = ((unsigned long long)(~k) << 32) | (unsigned long long)(uint32_t)i;
     }
 }
 
 __global__ void rank_take_kernel(const unsigned long long* __restrict__ skeys, const float* __restrict__ scores, int64_t topn,
                                  int32_t* __restrict__ out_pos, float* __restrict__ out_scores) {
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < topn; k += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t pos = 0xFFFFFFFFu - (uint32_t)(skeys[k] & 0xFFFFFFFFull);
+        const uint32_t pos = (uint32_t)(skeys[k] & 0xFFFFFFFFull);
         out_pos[k] = (int32_t)pos;
         if (out_scores) out_scores[k] = scores[pos];
     }
 }
 
-// workspace: [scores n][keys n x 8][sorted keys n x 8][bins 4096 + ctrl][rocPRIM temporary]
-static size_t rank_sort_temp_bytes(int64_t n) {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_keys_desc(nullptr, bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)n, 0, 64,
-                                        (hipStream_t)0);
-    return bytes;
-}
-
+// workspace: [scores n][keys n x 8][sorted keys n x 8][bins 4096 + ctrl][histograms of the sort]
 int64_t wmf_rank_ws_bytes(int64_t n) {
     if (n <= 0) return 256;
     const size_t arr = (((size_t)n * 4 + 255) / 256) * 256;
-    return (int64_t)(5 * arr + 4096 * 4 + 256 + rank_sort_temp_bytes(n) + 256);
+    return (int64_t)(5 * arr + 4096 * 4 + 256 + wmf_sort_ws_bytes(n) + 256);
 }
 
 int wmf_launch_rank(const float* users, const float* items, int f, int ld, int bias, const int32_t* user_idx,
@@ -266,11 +262,9 @@ int wmf_launch_rank(const float* users, const float* items, int f, int ld, int b
     if (hipMemcpyAsync(host_ctrl, ctrl, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
     const size_t m = host_ctrl[1];
     if ((int64_t)m < topn || (int64_t)m > n) return -2;
-    size_t temp_bytes = rank_sort_temp_bytes(n);
-    {
-        WmfProfScope ps("rocprim::radix_sort_keys_desc (rank)", st);
-        if (rocprim::radix_sort_keys_desc(temp, temp_bytes, keys, skeys, m, 0, 64, st) != hipSuccess) return -2;
-    }
+    bool in_alt = false;
+    if (wmf_sort_u64(keys, skeys, nullptr, nullptr, (int64_t)m, 64, temp, st, &in_alt)) return -2;
+    if (!in_alt) skeys = keys;
     hipLaunchKernelGGL(rank_take_kernel, dim3((unsigned)((topn + 255) / 256 > 1024 ? 1024 : (topn + 255) / 256)), dim3(256), 0, st,
                        skeys, scores, topn, out_pos, out_scores);
     return 0;

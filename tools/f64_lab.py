@@ -8,6 +8,8 @@ from recmodel_amd import _lib
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 lib = _lib.load()
+if len(sys.argv) > 2:
+    lib.wmf_debug_set_flags(int(sys.argv[2]))
 dev = torch.device("cuda:0")
 lib.wmf_profile_reset()
 lib.wmf_profile_enable(1)
