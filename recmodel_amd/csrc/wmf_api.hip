@@ -97,8 +97,9 @@ extern "C" {
 
 int wmf_debug_set_flags(int flags) {
 #ifndef WMF_LAB
-    // Ablation switches that make results WRONG (1, 2, 8) exist only in a -DWMF_LAB build (tools/build_variant.sh)
-    if (flags & (1 | 2 | 8)) { wmf_set_error("wmf_debug_set_flags: ablation flags 1/2/8 need a -DWMF_LAB build"); return WMF_EINVAL; }
+    // Ablation switches that make results WRONG (1, 2, 8) and the f32-MFMA accumulation of the LDS-DMA kernel (8192) exist only
+    // in a -DWMF_LAB build (tools/build_variant.sh)
+    if (flags & (1 | 2 | 8 | 8192)) { wmf_set_error("wmf_debug_set_flags: flags 1/2/8/8192 need a -DWMF_LAB build"); return WMF_EINVAL; }
 #endif
     wmf_debug_flags = flags;
     return WMF_OK;

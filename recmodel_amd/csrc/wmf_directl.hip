@@ -308,7 +308,8 @@ __global__ __launch_bounds__(64, (NFB <= 4 || GE == 8) ? 2 : 1) void solve_direc
             };
             auto kstep = [&](auto tc) {
                 constexpr int t = decltype(tc)::value, B = t & 1;
-                if (t >= nk) return;                             // wave-uniform: past the row's end
+                if (t > 0 && t >= nk) return;                    // wave-uniform: past the row's end (nk >= 1: k-step 0, whose reads are
+                                                                 // requested unconditionally below, always runs and waits for them)
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[B]), "+v"(xb[B]), "+v"(wv[B]), "+v"(bf[B]), "+v"(bb[B])::"memory");
                 const f32x4 ya = xa[B], yb = xb[B];
                 const float wraw = split ? wv[B] - bb[B] : wv[B], bfv = bf[B];
@@ -573,12 +574,20 @@ int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const
     const int64_t cap = 256 * 4 * (nfb <= 4 ? 2 : 1) * 3;        // resident waves, three rounds queued
     const dim3 grid((unsigned)(count < cap ? count : cap));
     const int dbg = wmf_debug_flags;
-    const bool x6 = !(dbg & 8192);                              // debug flag 8192: f32 MFMA accumulation
+#ifdef WMF_LAB
+    const bool x6 = !(dbg & 8192);                              // debug flag 8192 (lab builds only): f32 MFMA accumulation
+#else
+    constexpr bool x6 = true;                                   // (the f32-MFMA accumulation variants are compiled into -DWMF_LAB builds only)
+#endif
 #define DL_LAUNCH(N, B, X) WMF_LAUNCH("solve_directl_kernel<" #N ", " #B ", " #X ", 16, 0>", (solve_directl_kernel<N, B, X>), grid, dim3(64), \
                                       DL_LDSB(N, 16), st, rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, \
                                       (const int64_t*)nullptr, (const int32_t*)nullptr, (float*)nullptr)
+#ifdef WMF_LAB
 #define DL_PICK(N) do { if (f % 16) { if (x6) DL_LAUNCH(N, true, true); else DL_LAUNCH(N, true, false); } \
                         else        { if (x6) DL_LAUNCH(N, false, true); else DL_LAUNCH(N, false, false); } } while (0)
+#else
+#define DL_PICK(N) do { if (f % 16) DL_LAUNCH(N, true, true); else DL_LAUNCH(N, false, true); } while (0)
+#endif
     if (nfb == 4) DL_PICK(4);
     else if (x6 && !(dbg & 16777216)) {
         // k = 128: 8-entry groups (16 KB ring, 16-entry chunks with 16x16x16 MFMAs, w_p in LDS by inline asm, lane coordinates

@@ -1,7 +1,7 @@
 """Full-scale cross-check of the heavy-row kernels (not a test): one half step of a bench configuration's side, solved by
 every variant the debug flags select, ALL rows compared against the first (row-wise relative difference).  Catches what a
 sample of rows cannot: a rare race between consecutive rows of one wave.
-Usage: python tools/compare_heavy_variants.py cfg3 items 0,8192,4096 [repeats]"""
+Usage: python tools/compare_heavy_variants.py cfg3 items 0,4096 [repeats]   (8192, the f32-MFMA accumulation, needs a -DWMF_LAB build)"""
 import ctypes, sys
 import numpy as np, torch
 sys.path.insert(0, '.')
@@ -10,7 +10,7 @@ from recmodel_amd.engine import AlsEngine, _ptr, _stream
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 side = sys.argv[2] if len(sys.argv) > 2 else "items"
-flags = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "0,8192,4096").split(",")]
+flags = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "0,4096").split(",")]
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 lib = _lib.load()
 n_users, n_items, dbar, k, bias = synth.CONFIGS[cfg]
