@@ -31,6 +31,7 @@
 // f4 = ceil(f / 4) block rows; row bi holds the blocks (bi, bi) .. (bi, f4 - 1) and, when RHS, one more at column f4: the
 // right-hand side (its first column; the other three stay zero).  Block number b = n * 256 + thread, n < NB.
 #define F64_R 16                                   /* gathered entries (or rows of Y) staged per pass */
+#define F64_LR_D 32                                /* rows with at most this many entries take the low-rank form (solve64lr_kernel) */
 __device__ __forceinline__ void f64_decode(int b, int f4, bool rhs, int& bi, int& bj) {
     int r = 0, rem = b;
     const int extra = rhs ? 1 : 0;
@@ -154,6 +155,144 @@ __device__ __forceinline__ double f64_rsqrt(double x) {
     }
     return y;
 }
+// ---- the two phases every row system goes through, on the 4 x 4 blocks of a TEAM (solve64v2_kernel, solve64lr_kernel,
+// factor64_kernel).  f4 = block rows / columns of the matrix; block column f4 is the right-hand side (RHS) or does not exist.
+// Right-looking blocked Cholesky A = R^T R on the registers; with a right-hand side, yv = R^-T b when it returns.
+template <int NB, int TEAM>
+__device__ __forceinline__ bool f64_cholesky(double (&acc)[NB][16], const int (&bi)[NB], const int (&bj)[NB], const bool (&on)[NB], int f4,
+                                             double* __restrict__ panel, double* __restrict__ dbuf, double* __restrict__ yv) {
+    bool bad = false;
+#pragma unroll 1
+    for (int kb = 0; kb < f4; ++kb) {
+        double* pan = panel + (kb & 1) * (f4 + 1) * 16;
+        double* db = dbuf + (kb & 1) * 16;
+#pragma unroll
+        for (int n_ = 0; n_ < NB; ++n_) {
+            if (on[n_] && bi[n_] == kb && bj[n_] == kb) {        // (a) the diagonal block: R_kk, then its inverse (upper triangular)
+                double* a = acc[n_];
+                double r[4][4], iv[4][4], rinv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double dgl = a[5 * i];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) dgl -= r[k][i] * r[k][i];
+                    if (!(dgl > 0.0) || !(dgl < 1.0e300)) { bad = true; dgl = 1.0; }   // not positive definite (or not finite)
+                    const double inv = f64_rsqrt(dgl);
+                    rinv[i] = inv;
+                    r[i][i] = dgl * inv;
+#pragma unroll
+                    for (int j = i + 1; j < 4; ++j) {
+                        double v = a[4 * i + j];
+#pragma unroll
+                        for (int k = 0; k < i; ++k) v -= r[k][i] * r[k][j];
+                        r[i][j] = v * inv;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) iv[i][j] = 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    iv[j][j] = rinv[j];
+#pragma unroll
+                    for (int i = j - 1; i >= 0; --i) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int k = i + 1; k <= j; ++k) v += r[i][k] * iv[k][j];
+                        iv[i][j] = -v * rinv[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { a[i] = iv[i >> 2][i & 3]; db[i] = a[i]; }   // the owner keeps R_kk^-1 (back substitution; factor64: R^-1)
+            }
+        }
+        f64_team_sync<TEAM>();
+#pragma unroll
+        for (int n_ = 0; n_ < NB; ++n_) {
+            if (on[n_] && bi[n_] == kb && bj[n_] > kb) {         // (b) block row kb: R_kj = R_kk^-T A_kj
+                double* a = acc[n_];
+                double u[16];
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int k = 0; k <= x; ++k) v += db[4 * k + x] * a[4 * k + y];
+                        u[4 * x + y] = v;
+                    }
+                double2* o = reinterpret_cast<double2*>(pan + bj[n_] * 16);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = make_double2(u[2 * i], u[2 * i + 1]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a[i] = u[i];
+                if (bj[n_] == f4) {                              // y_kb = (R^-T b)_kb: where the back substitution starts
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) yv[4 * kb + x] = u[4 * x];
+                }
+            }
+        }
+        f64_team_sync<TEAM>();
+#pragma unroll
+        for (int n_ = 0; n_ < NB; ++n_) {
+            if (on[n_] && bi[n_] > kb) {                         // (c) trailing update A_ij -= R_ki^T R_kj
+                const double* ui = pan + bi[n_] * 16;
+                const double* uj = pan + bj[n_] * 16;
+                double* a = acc[n_];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double2 i01 = *reinterpret_cast<const double2*>(ui + 4 * k), i23 = *reinterpret_cast<const double2*>(ui + 4 * k + 2);
+                    const double2 j01 = *reinterpret_cast<const double2*>(uj + 4 * k), j23 = *reinterpret_cast<const double2*>(uj + 4 * k + 2);
+                    const double iv_[4] = {i01.x, i01.y, i23.x, i23.y};
+                    const double jv_[4] = {j01.x, j01.y, j23.x, j23.y};
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) a[4 * x + y] = __builtin_fma(-iv_[x], jv_[y], a[4 * x + y]);
+                }
+            }
+        }
+    }
+    return bad;
+}
+
+// Back substitution R x = yv, block column by block column; every R block is still in its owner's registers (diagonal blocks
+// hold R_kk^-1).  x (nx values) goes to xout[i * xstride]; yv and xs are the team's LDS vectors.
+template <int NB, int TEAM>
+__device__ __forceinline__ void f64_backsub(const double (&acc)[NB][16], const int (&bi)[NB], const int (&bj)[NB], const bool (&on)[NB], int f4,
+                                            double* __restrict__ yv, double* __restrict__ xs, double* __restrict__ xout, int nx) {
+#pragma unroll 1
+    for (int kb = f4 - 1; kb >= 0; --kb) {
+#pragma unroll
+        for (int n_ = 0; n_ < NB; ++n_) {
+            if (on[n_] && bi[n_] == kb && bj[n_] == kb) {
+                const double* iv = acc[n_];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int j = i; j < 4; ++j) v += iv[4 * i + j] * yv[4 * kb + j];
+                    xs[i] = v;
+                    if (4 * kb + i < nx) xout[4 * kb + i] = v;
+                }
+            }
+        }
+        f64_team_sync<TEAM>();
+#pragma unroll
+        for (int n_ = 0; n_ < NB; ++n_) {
+            if (on[n_] && bj[n_] == kb && bi[n_] < kb) {         // y_bi -= R_(bi, kb) x_kb: one owner per (bi, kb)
+                const double* u = acc[n_];
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    yv[4 * bi[n_] + x] -= u[4 * x] * xs[0] + u[4 * x + 1] * xs[1] + u[4 * x + 2] * xs[2] + u[4 * x + 3] * xs[3];
+            }
+        }
+        f64_team_sync<TEAM>();
+    }
+}
+
 #ifndef F64_WAVE_TEAM_OCC
 #define F64_WAVE_TEAM_OCC 3      /* workgroups per CU the wave-team variants are compiled for (168 registers) */
 #endif
@@ -161,9 +300,11 @@ template <int NB, int TEAM, int R>
 __global__ __launch_bounds__(256, TEAM == 64 ? F64_WAVE_TEAM_OCC : 1) void solve64v2_kernel(const double* __restrict__ Y, int f, int bias, const double* __restrict__ G,
                                                         const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                         const double* __restrict__ vals, int64_t n, double* __restrict__ X,
-                                                        int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int team_doubles) {
+                                                        int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int team_doubles,
+                                                        const int32_t* __restrict__ ctrl) {
     extern __shared__ __attribute__((aligned(16))) double sm64[];
     constexpr int NTEAM = 256 / TEAM;
+    const bool lowrank_on = ctrl[0] != 0;                            // rows with 1 .. F64_LR_D entries go through solve64lr_kernel then
     const int t = threadIdx.x & (TEAM - 1);
     const int tw = TEAM == 256 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int f4 = (f + 3) >> 2, FP = 4 * f4, FPA = FP + 4, nblk = f4 * (f4 + 1) / 2 + f4;
@@ -190,6 +331,7 @@ __global__ __launch_bounds__(256, TEAM == 64 ? F64_WAVE_TEAM_OCC : 1) void solve
             for (int c = t; c < f; c += TEAM) X[row * f + c] = 0.0;
             continue;
         }
+        if (lowrank_on && hi - lo <= F64_LR_D) continue;
         double acc[NB][16];
 #pragma unroll
         for (int n_ = 0; n_ < NB; ++n_)
@@ -229,101 +371,8 @@ __global__ __launch_bounds__(256, TEAM == 64 ? F64_WAVE_TEAM_OCC : 1) void solve
                     else if (gi == gj) acc[n_][4 * x + y] += 1.0;
                 }
         }
-        // ---- right-looking blocked Cholesky A = R^T R on the registers, b riding along as block column f4
-        bool bad = false;
-#pragma unroll 1
-        for (int kb = 0; kb < f4; ++kb) {
-            double* pan = panel + (kb & 1) * (f4 + 1) * 16;
-            double* db = dbuf + (kb & 1) * 16;
-#pragma unroll
-            for (int n_ = 0; n_ < NB; ++n_) {
-                if (on[n_] && bi[n_] == kb && bj[n_] == kb) {        // (a) the diagonal block: R_kk, then its inverse (upper triangular)
-                    double* a = acc[n_];
-                    double r[4][4], iv[4][4], rinv[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        double dgl = a[5 * i];
-#pragma unroll
-                        for (int k = 0; k < i; ++k) dgl -= r[k][i] * r[k][i];
-                        if (!(dgl > 0.0) || !(dgl < 1.0e300)) { bad = true; dgl = 1.0; }   // not positive definite (or not finite): the LU kernel takes the row
-                        const double inv = f64_rsqrt(dgl);
-                        rinv[i] = inv;
-                        r[i][i] = dgl * inv;
-#pragma unroll
-                        for (int j = i + 1; j < 4; ++j) {
-                            double v = a[4 * i + j];
-#pragma unroll
-                            for (int k = 0; k < i; ++k) v -= r[k][i] * r[k][j];
-                            r[i][j] = v * inv;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) iv[i][j] = 0.0;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        iv[j][j] = rinv[j];
-#pragma unroll
-                        for (int i = j - 1; i >= 0; --i) {
-                            double v = 0.0;
-#pragma unroll
-                            for (int k = i + 1; k <= j; ++k) v += r[i][k] * iv[k][j];
-                            iv[i][j] = -v * rinv[i];
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { a[i] = iv[i >> 2][i & 3]; db[i] = a[i]; }   // the owner keeps R_kk^-1 for the back substitution
-                }
-            }
-            f64_team_sync<TEAM>();
-#pragma unroll
-            for (int n_ = 0; n_ < NB; ++n_) {
-                if (on[n_] && bi[n_] == kb && bj[n_] > kb) {         // (b) block row kb: R_kj = R_kk^-T A_kj
-                    double* a = acc[n_];
-                    double u[16];
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-#pragma unroll
-                        for (int y = 0; y < 4; ++y) {
-                            double v = 0.0;
-#pragma unroll
-                            for (int k = 0; k <= x; ++k) v += db[4 * k + x] * a[4 * k + y];
-                            u[4 * x + y] = v;
-                        }
-                    double2* o = reinterpret_cast<double2*>(pan + bj[n_] * 16);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) o[i] = make_double2(u[2 * i], u[2 * i + 1]);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) a[i] = u[i];
-                    if (bj[n_] == f4) {                              // y_kb = (R^-T b)_kb: where the back substitution starts
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) yv[4 * kb + x] = u[4 * x];
-                    }
-                }
-            }
-            f64_team_sync<TEAM>();
-#pragma unroll
-            for (int n_ = 0; n_ < NB; ++n_) {
-                if (on[n_] && bi[n_] > kb) {                         // (c) trailing update A_ij -= R_ki^T R_kj
-                    const double* ui = pan + bi[n_] * 16;
-                    const double* uj = pan + bj[n_] * 16;
-                    double* a = acc[n_];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const double2 i01 = *reinterpret_cast<const double2*>(ui + 4 * k), i23 = *reinterpret_cast<const double2*>(ui + 4 * k + 2);
-                        const double2 j01 = *reinterpret_cast<const double2*>(uj + 4 * k), j23 = *reinterpret_cast<const double2*>(uj + 4 * k + 2);
-                        const double iv_[4] = {i01.x, i01.y, i23.x, i23.y};
-                        const double jv_[4] = {j01.x, j01.y, j23.x, j23.y};
-#pragma unroll
-                        for (int x = 0; x < 4; ++x)
-#pragma unroll
-                            for (int y = 0; y < 4; ++y) a[4 * x + y] = __builtin_fma(-iv_[x], jv_[y], a[4 * x + y]);
-                    }
-                }
-            }
-        }
+        // ---- blocked Cholesky A = R^T R on the registers (b rides along), then the back substitution
+        const bool bad = f64_cholesky<NB, TEAM>(acc, bi, bj, on, f4, panel, dbuf, yv);
         bool give_up;
         if constexpr (TEAM == 256) {
             if (bad) *flag = 1;
@@ -337,34 +386,264 @@ __global__ __launch_bounds__(256, TEAM == 64 ? F64_WAVE_TEAM_OCC : 1) void solve
             if (t == 0) fb_rows[atomicAdd(fb_count, 1)] = (int32_t)row;
             continue;
         }
-        // ---- back substitution R x = y, block column by block column; every R block is still in its owner's registers
-#pragma unroll 1
-        for (int kb = f4 - 1; kb >= 0; --kb) {
+        f64_backsub<NB, TEAM>(acc, bi, bj, on, f4, yv, xs, X + row * f, f);
+    }
+}
+
+// ---- the low-rank form in float64 for rows with few entries ---------------------------------------------------------------------
+// The same push-through identity as the float32 path, in float64: with G = R^T R and V = Y~ R^-1,
+//     x_u = R^-1 g_u,   g_u = V_u^T c,   c = E y,   (I + E S E) y = E^-1 p,   S = V_u V_u^T,  E = diag(sqrt(w)),  p = w + 1
+// -- a d x d system (d <= 32: eight block columns instead of f / 4) built from ONE gather of d whitened rows.  Used when at
+// least a quarter of the rows of a half step have 1 .. 32 entries (f64_decide_kernel); rows with a negative weight (bias
+// models) or a system that is not positive definite go to the pivoted LU kernel like everywhere else.
+//   factor64_kernel<NB>   G = R^T R by the blocked Cholesky above (one workgroup); blocks of R, diagonal blocks inverted
+//   rinv64_kernel         R^-1 and R^-T, one thread per column, block back substitution
+//   transform64_kernel    out = in~ . W (whitening V = Y~ R^-1; un-whitening X = g R^-T for the rows that took this path)
+//   solve64lr_kernel      the row systems, one wave per row
+#define F64_LR_RJ 16
+__global__ void f64_count_low_kernel(const int64_t* __restrict__ indptr, int64_t n, int32_t* __restrict__ ctrl) {
+    int c = 0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d = indptr[r + 1] - indptr[r];
+        c += (d >= 1 && d <= F64_LR_D) ? 1 : 0;
+    }
 #pragma unroll
-            for (int n_ = 0; n_ < NB; ++n_) {
-                if (on[n_] && bi[n_] == kb && bj[n_] == kb) {
-                    const double* iv = acc[n_];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&ctrl[1], c);
+}
+// ctrl[0] = 1: the low-rank path is on for this half step (enough rows for the whitening pass to pay, debug flag not set)
+__global__ void f64_decide_kernel(int32_t* __restrict__ ctrl, int64_t n, int off) {
+    ctrl[0] = (!off && (int64_t)ctrl[1] * 4 >= n && n > 0) ? 1 : 0;
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void factor64_kernel(const double* __restrict__ G, int f, double* __restrict__ Rblk, int32_t* __restrict__ ctrl) {
+    extern __shared__ __attribute__((aligned(16))) double sm64[];
+    if (ctrl[0] == 0) return;
+    const int t = threadIdx.x;
+    const int f4 = (f + 3) >> 2, nblk = f4 * (f4 + 1) / 2;
+    double* panel = sm64;                           // [2][(f4 + 1) * 16]
+    double* dbuf = panel + 2 * (f4 + 1) * 16;       // [2][16]
+    double* yv = dbuf + 32;                         // unused (no right-hand side)
+    int* flag = reinterpret_cast<int*>(yv + 4);
+    int bi[NB], bj[NB];
+    bool on[NB];
+    double acc[NB][16];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        double v = 0.0;
+    for (int n_ = 0; n_ < NB; ++n_) {
+        const int b = n_ * 256 + t;
+        on[n_] = b < nblk;
+        f64_decode(on[n_] ? b : 0, f4, false, bi[n_], bj[n_]);
 #pragma unroll
-                        for (int j = i; j < 4; ++j) v += iv[4 * i + j] * yv[4 * kb + j];
-                        xs[i] = v;
-                        if (4 * kb + i < f) X[row * f + 4 * kb + i] = v;
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const int gi = 4 * bi[n_] + x, gj = 4 * bj[n_] + y;
+                acc[n_][4 * x + y] = (on[n_] && gi < f && gj < f) ? G[(int64_t)gi * f + gj] : ((gi == gj) ? 1.0 : 0.0);
+            }
+    }
+    if (t == 0) *flag = 0;
+    __syncthreads();
+    const bool bad = f64_cholesky<NB, 256>(acc, bi, bj, on, f4, panel, dbuf, yv);
+    if (bad) *flag = 1;
+    __syncthreads();
+    if (*flag) { if (t == 0) ctrl[0] = 0; return; }             // G + lambda I not positive definite: every row takes the direct kernel
+#pragma unroll
+    for (int n_ = 0; n_ < NB; ++n_) {
+        if (!on[n_]) continue;
+        double2* o = reinterpret_cast<double2*>(Rblk + ((int64_t)bi[n_] * f4 + bj[n_]) * 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = make_double2(acc[n_][2 * i], acc[n_][2 * i + 1]);
+    }
+}
+
+// column j of R^-1 by block back substitution on the blocks of factor64_kernel (diagonal blocks hold R_kk^-1); written as
+// Rinv[i][j] and RinvT[j][i], both [FP][FP], zero outside the f x f upper / lower triangle
+__global__ __launch_bounds__(64) void rinv64_kernel(const double* __restrict__ Rblk, int f, double* __restrict__ Rinv, double* __restrict__ RinvT,
+                                                    const int32_t* __restrict__ ctrl) {
+    if (ctrl[0] == 0) return;
+    const int f4 = (f + 3) >> 2, FP = 4 * f4;
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= FP) return;
+    for (int i = 0; i < FP; ++i) { Rinv[(int64_t)i * FP + j] = 0.0; RinvT[(int64_t)j * FP + i] = 0.0; }
+    if (j >= f) return;
+    const int jb = j >> 2;
+    for (int kb = jb; kb >= 0; --kb) {
+        double rhs[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) rhs[x] = (4 * kb + x == j) ? 1.0 : 0.0;
+        for (int lb = kb + 1; lb <= jb; ++lb) {
+            const double* u = Rblk + ((int64_t)kb * f4 + lb) * 16;
+            double xl[4];
+#pragma unroll
+            for (int y = 0; y < 4; ++y) xl[y] = Rinv[(int64_t)(4 * lb + y) * FP + j];          // this thread's own earlier results
+#pragma unroll
+            for (int x = 0; x < 4; ++x) rhs[x] -= u[4 * x] * xl[0] + u[4 * x + 1] * xl[1] + u[4 * x + 2] * xl[2] + u[4 * x + 3] * xl[3];
+        }
+        const double* iv = Rblk + ((int64_t)kb * f4 + kb) * 16;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            double v = 0.0;
+#pragma unroll
+            for (int y = x; y < 4; ++y) v += iv[4 * x + y] * rhs[y];
+            Rinv[(int64_t)(4 * kb + x) * FP + j] = v;
+            RinvT[(int64_t)j * FP + 4 * kb + x] = v;
+        }
+    }
+}
+
+// out[r][0 .. f) = in~[r][0 .. f) . W, W [FP][FP] row-major (zero padded); in~ = in with column 0 read as 1 when set_col0_one.
+// indptr != NULL: only the rows with 1 .. F64_LR_D stored entries are written (the un-whitening of the low-rank rows).
+template <int NB>
+__global__ __launch_bounds__(256) void transform64_kernel(const double* __restrict__ in, int64_t m, int f, const double* __restrict__ W,
+                                                          int set_col0_one, double* __restrict__ out, const int64_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ ctrl, int64_t rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) double sm64[];
+    if (ctrl[0] == 0) return;
+    const int t = threadIdx.x;
+    const int f4 = (f + 3) >> 2, FP = 4 * f4, LDR = FP + 1, nblk = 4 * f4;      // odd row stride: the four rows of a block on distinct banks
+    double* ys = sm64;                              // [16][LDR]
+    int rb[NB], cb[NB];
+    bool on[NB];
+#pragma unroll
+    for (int n_ = 0; n_ < NB; ++n_) { const int b = n_ * 256 + t; on[n_] = b < nblk; rb[n_] = b & 3; cb[n_] = on[n_] ? b >> 2 : 0; }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(m, r0 + rows_per_block);
+    for (int64_t c0 = r0; c0 < r1; c0 += 16) {
+        const int nvalid = (int)min((int64_t)16, r1 - c0);
+        __syncthreads();
+        for (int i = t; i < 16 * FP; i += 256) {
+            const int e = i / FP, c = i - e * FP;
+            double v = 0.0;
+            if (e < nvalid && c < f) v = (set_col0_one && c == 0) ? 1.0 : in[(c0 + e) * f + c];
+            ys[e * LDR + c] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n_ = 0; n_ < NB; ++n_) {
+            if (!on[n_]) continue;
+            double acc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+            const double* a0 = ys + (4 * rb[n_]) * LDR;
+            const double* wcol = W + 4 * cb[n_];
+            for (int k = 0; k < f; ++k) {
+                const double2 w01 = *reinterpret_cast<const double2*>(wcol + (int64_t)k * FP), w23 = *reinterpret_cast<const double2*>(wcol + (int64_t)k * FP + 2);
+                const double w[4] = {w01.x, w01.y, w23.x, w23.y};
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const double a = a0[x * LDR + k];
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) acc[4 * x + y] = __builtin_fma(a, w[y], acc[4 * x + y]);
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int e = 4 * rb[n_] + x;
+                if (e >= nvalid) continue;
+                const int64_t row = c0 + e;
+                if (indptr) { const int64_t d = indptr[row + 1] - indptr[row]; if (d < 1 || d > F64_LR_D) continue; }
+#pragma unroll
+                for (int y = 0; y < 4; ++y) { const int c = 4 * cb[n_] + y; if (c < f) out[row * f + c] = acc[4 * x + y]; }
+            }
+        }
+    }
+}
+
+// one WAVE per row with 1 .. 32 stored entries.  LDS per wave (doubles): ys [16][36] | ones [16] | panel [2][9 * 16] | dbuf [32] | yv [32] |
+// xs [4] | ev [32] | tv [32] | cv [32] | ib (int) [32]
+#define F64_LR_TEAM_DOUBLES 1080
+__global__ __launch_bounds__(256) void solve64lr_kernel(const double* __restrict__ V, const double* __restrict__ Y, int f, int bias,
+                                                        const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                        const double* __restrict__ vals, int64_t n, double* __restrict__ gout,
+                                                        int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count,
+                                                        const int32_t* __restrict__ ctrl) {
+    extern __shared__ __attribute__((aligned(16))) double sm64[];
+    if (ctrl[0] == 0) return;
+    constexpr int f4 = F64_LR_D / 4, LDY = F64_LR_D + 4;
+    const int t = threadIdx.x & 63;
+    const int tw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* ys = sm64 + (size_t)tw * F64_LR_TEAM_DOUBLES;
+    double* ones = ys + F64_LR_RJ * LDY;
+    double* panel = ones + F64_LR_RJ;
+    double* dbuf = panel + 2 * (f4 + 1) * 16;
+    double* yv = dbuf + 32;
+    double* xs = yv + F64_LR_D;
+    double* ev = xs + 4;
+    double* tv = ev + F64_LR_D;
+    double* cv = tv + F64_LR_D;
+    int* ib = reinterpret_cast<int*>(cv + F64_LR_D);
+    int bi[1], bj[1];
+    bool on[1];
+    on[0] = t < f4 * (f4 + 1) / 2 + f4;
+    f64_decode(on[0] ? t : 0, f4, true, bi[0], bj[0]);
+    if (t < F64_LR_RJ) ones[t] = 1.0;
+    for (int i = t; i < F64_LR_RJ * 4; i += 64) ys[(i >> 2) * LDY + F64_LR_D + (i & 3)] = 0.0;     // the right-hand-side columns stay zero
+    for (int64_t row = (int64_t)blockIdx.x * 4 + tw; row < n; row += (int64_t)gridDim.x * 4) {
+        const int64_t lo = indptr[row], hi = indptr[row + 1];
+        const int d = (int)min(hi - lo, (int64_t)(F64_LR_D + 1));
+        if (d < 1 || d > F64_LR_D) continue;
+        f64_team_sync<64>();                                         // the previous row is done with the LDS vectors
+        bool neg = false;
+        if (t < F64_LR_D) {
+            const bool real = t < d;
+            const int idx = indices[real ? lo + t : lo];
+            const double w = real ? vals[lo + t] - (bias ? Y[(int64_t)idx * f] : 0.0) : 1.0;      // data - bias[idx], :279
+            if (real && !(w >= 0.0)) neg = true;                     // negative (or NaN) weight: E = sqrt(w) does not exist
+            const double wc = w > 1.0e-300 ? w : 1.0e-300;            // a stored zero: p = 1 still counts (wmf_model.py:232,239)
+            const double e = sqrt(wc);
+            ib[t] = idx;
+            ev[t] = real ? e : 1.0;
+            tv[t] = real ? (w + 1.0) / e : 0.0;                      // E^-1 p
+        }
+        if (__any(neg)) {                                            // uniform: the pivoted kernel takes the row
+            if (t == 0) fb_rows[atomicAdd(fb_count, 1)] = (int32_t)row;
+            continue;
+        }
+        double acc[1][16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][i] = 0.0;
+        // ---- S = V_u V_u^T over the features, F64_LR_RJ at a time (staged feature-major: ys[feature][entry])
+        for (int j0 = 0; j0 < f; j0 += F64_LR_RJ) {
+            const int nv = min(F64_LR_RJ, f - j0);
+            f64_team_sync<64>();
+            for (int i = t; i < F64_LR_RJ * F64_LR_D; i += 64) {
+                const int e = i / F64_LR_RJ, jj = i - e * F64_LR_RJ;                 // consecutive lanes: consecutive features of one entry
+                ys[jj * LDY + e] = (e < d && jj < nv) ? V[(int64_t)ib[e] * f + j0 + jj] : 0.0;
+            }
+            f64_team_sync<64>();
+            f64_accumulate<1>(acc, bi, bj, on, ys, LDY, ones, nv, f4);
+        }
+        // ---- P = I + E S E, right-hand side E^-1 p
+        if (on[0]) {
+            if (bj[0] < f4) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) {
+                        const int gi = 4 * bi[0] + x, gj = 4 * bj[0] + y;
+                        acc[0][4 * x + y] = ev[gi] * acc[0][4 * x + y] * ev[gj] + (gi == gj ? 1.0 : 0.0);
                     }
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    acc[0][4 * x] = tv[4 * bi[0] + x];
+                    acc[0][4 * x + 1] = 0.0; acc[0][4 * x + 2] = 0.0; acc[0][4 * x + 3] = 0.0;
                 }
             }
-            f64_team_sync<TEAM>();
-#pragma unroll
-            for (int n_ = 0; n_ < NB; ++n_) {
-                if (on[n_] && bj[n_] == kb && bi[n_] < kb) {         // y_bi -= R_(bi, kb) x_kb: one owner per (bi, kb)
-                    const double* u = acc[n_];
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        yv[4 * bi[n_] + x] -= u[4 * x] * xs[0] + u[4 * x + 1] * xs[1] + u[4 * x + 2] * xs[2] + u[4 * x + 3] * xs[3];
-                }
-            }
-            f64_team_sync<TEAM>();
+        }
+        const bool bad = f64_cholesky<1, 64>(acc, bi, bj, on, f4, panel, dbuf, yv);
+        if (__any(bad)) {
+            if (t == 0) fb_rows[atomicAdd(fb_count, 1)] = (int32_t)row;
+            continue;
+        }
+        f64_backsub<1, 64>(acc, bi, bj, on, f4, yv, xs, cv, F64_LR_D);          // y -> cv
+        if (t < F64_LR_D) cv[t] = t < d ? ev[t] * cv[t] : 0.0;                    // c = E y
+        f64_team_sync<64>();
+        // ---- g = V_u^T c (the second read of the d whitened rows: L2)
+        for (int j = t; j < f; j += 64) {
+            double sacc = 0.0;
+            for (int e = 0; e < d; ++e) sacc = __builtin_fma(V[(int64_t)ib[e] * f + j], cv[e], sacc);
+            gout[row * f + j] = sacc;
         }
     }
 }
@@ -482,10 +761,13 @@ static int gram64_blocks(int64_t m) {
 static int solve64_blocks(int64_t n) { return (int)(n < 1 ? 1 : (n > 4096 ? 4096 : n)); }
 #define WMF_F64_LU_GRID 256
 
-// workspace: [gram partials nwg x blocks x 16][G f x f][LU slices WMF_F64_LU_GRID x (f x f + f)] doubles [fallback rows n + 64 int32]
+// workspace: [gram partials nwg x blocks x 16][G f x f][LU slices WMF_F64_LU_GRID x (f x f + f)] doubles [64 int32: fallback count,
+// control words][fallback rows n int32][R blocks f4 x f4 x 16][R^-1 FP x FP][R^-T FP x FP][V m x f][g n x f] doubles
+static int64_t f64_al(int64_t bytes) { return (bytes + 255) / 256 * 256; }
 int64_t wmf_f64_ws_bytes(int f, int64_t m, int64_t n) {
-    const int64_t ff = (int64_t)f * f;
-    return 8 * ((int64_t)gram64_blocks(m) * f64_blocks(f, false) * 16 + ff + (int64_t)WMF_F64_LU_GRID * (ff + f)) + 4 * (n + 64) + 256;
+    const int64_t ff = (int64_t)f * f, f4 = (f + 3) / 4, FP = 4 * f4;
+    return f64_al(8 * ((int64_t)gram64_blocks(m) * f64_blocks(f, false) * 16 + ff + (int64_t)WMF_F64_LU_GRID * (ff + f))) + f64_al(4 * (n + 64)) +
+           f64_al(8 * f4 * f4 * 16) + 2 * f64_al(8 * FP * FP) + f64_al(8 * m * f) + f64_al(8 * (n > 0 ? n : 1) * f) + 256;
 }
 
 template <int NB>
@@ -507,7 +789,7 @@ static void launch_gram64(const double* Y, int64_t m, int f, int bias, double la
 
 template <int NB, int TEAM, int R>
 static void launch_solve64(const double* Y, int f, int bias, const double* G, const int64_t* indptr, const int32_t* indices,
-                           const double* values, int64_t n, double* X, int32_t* fb_rows, int32_t* fb_count, hipStream_t st) {
+                           const double* values, int64_t n, double* X, int32_t* fb_rows, int32_t* fb_count, const int32_t* ctrl, hipStream_t st) {
     const int team_doubles = (int)((solve64v2_team_doubles(f, R) + 1) & ~(size_t)1);           // 16-byte aligned slices
     const size_t lds = (size_t)team_doubles * 8 * (256 / TEAM);
     static bool attr_set = false;
@@ -520,18 +802,56 @@ static void launch_solve64(const double* Y, int f, int bias, const double* G, co
     int64_t grid = (n + teams - 1) / teams;
     if (grid > 4096) grid = 4096;
     WMF_LAUNCH(nms, (solve64v2_kernel<NB, TEAM, R>), dim3((unsigned)grid), dim3(256), lds, st, Y, f, bias, G, indptr, indices, values, n,
-               X, fb_rows, fb_count, team_doubles);
+               X, fb_rows, fb_count, team_doubles, ctrl);
+}
+
+template <int NB>
+static void launch_factor64(const double* G, int f, double* Rblk, int32_t* ctrl, hipStream_t st) {
+    const int f4 = (f + 3) / 4;
+    static const char* nm = wmf_kname("factor64_kernel<%d>", NB);
+    WMF_LAUNCH(nm, (factor64_kernel<NB>), dim3(1), dim3(256), (size_t)(2 * (f4 + 1) * 16 + 32 + 8) * 8, st, G, f, Rblk, ctrl);
+}
+
+template <int NB>
+static void launch_transform64(const double* in, int64_t m, int f, const double* W, int set_col0_one, double* out, const int64_t* indptr,
+                               const int32_t* ctrl, hipStream_t st) {
+    if (m <= 0) return;
+    const int f4 = (f + 3) / 4, FP = 4 * f4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)transform64_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    int64_t grid = (m + 63) / 64;                   // at least four 16-row passes per workgroup
+    if (grid > 2048) grid = 2048;
+    const int64_t rpb = ((m + grid - 1) / grid + 15) / 16 * 16;
+    static const char* nm = wmf_kname("transform64_kernel<%d>", NB);
+    WMF_LAUNCH(nm, (transform64_kernel<NB>), dim3((unsigned)((m + rpb - 1) / rpb)), dim3(256), (size_t)16 * (FP + 1) * 8, st, in, m, f, W,
+               set_col0_one, out, indptr, ctrl, rpb);
 }
 
 int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const int64_t* indptr, const int32_t* indices,
                              const double* values, int64_t n, double lambda, double* X, void* ws, int32_t* fail, hipStream_t st) {
-    const int64_t ff = (int64_t)f * f;
+    const int64_t ff = (int64_t)f * f, f4 = (f + 3) / 4, FP = 4 * f4;
     const int nwg = gram64_blocks(m);
-    double* partial = static_cast<double*>(ws);
+    char* base = static_cast<char*>(ws);
+    double* partial = reinterpret_cast<double*>(base);
     double* G = partial + (int64_t)nwg * f64_blocks(f, false) * 16;
     double* slices = G + ff;
-    int32_t* fb_count = reinterpret_cast<int32_t*>(slices + (int64_t)WMF_F64_LU_GRID * (ff + f));
+    base += f64_al(8 * ((int64_t)nwg * f64_blocks(f, false) * 16 + ff + (int64_t)WMF_F64_LU_GRID * (ff + f)));
+    int32_t* fb_count = reinterpret_cast<int32_t*>(base);
+    int32_t* ctrl = fb_count + 16;                  // [0] low-rank path on, [1] rows with 1 .. F64_LR_D entries
     int32_t* fb_rows = fb_count + 64;
+    base += f64_al(4 * (n + 64));
+    double* Rblk = reinterpret_cast<double*>(base);
+    base += f64_al(8 * f4 * f4 * 16);
+    double* Rinv = reinterpret_cast<double*>(base);
+    base += f64_al(8 * FP * FP);
+    double* RinvT = reinterpret_cast<double*>(base);
+    base += f64_al(8 * FP * FP);
+    double* V = reinterpret_cast<double*>(base);
+    base += f64_al(8 * m * f);
+    double* gbuf = reinterpret_cast<double*>(base);
     if (hipMemsetAsync(fb_count, 0, 256, st) != hipSuccess) return -2;
     switch (f64_nb(f64_blocks(f, false))) {
 #define C_(N) case N: launch_gram64<N>(Y, m, f, bias, lambda, partial, G, nwg, st); break;
@@ -540,8 +860,36 @@ int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const 
         default: return -1;
     }
     if (n > 0) {
+        // ---- rows with 1 .. 32 entries through the whitened low-rank form, when there are enough of them (debug flag 134217728: never)
+        int64_t cgrid = (n + 255) / 256;
+        if (cgrid > 1024) cgrid = 1024;
+        hipLaunchKernelGGL(f64_count_low_kernel, dim3((unsigned)cgrid), dim3(256), 0, st, indptr, n, ctrl);
+        hipLaunchKernelGGL(f64_decide_kernel, dim3(1), dim3(1), 0, st, ctrl, n, (wmf_debug_flags & 134217728) ? 1 : 0);
+        switch (f64_nb(f64_blocks(f, false))) {
+#define C_(N) case N: launch_factor64<N>(G, f, Rblk, ctrl, st); break;
+            C_(1) C_(2) C_(3) C_(5) C_(9)
+#undef C_
+            default: return -1;
+        }
+        WMF_LAUNCH("rinv64_kernel", rinv64_kernel, dim3((unsigned)((FP + 63) / 64)), dim3(64), 0, st, Rblk, f, Rinv, RinvT, ctrl);
+        if (4 * f4 <= 256) launch_transform64<1>(Y, m, f, Rinv, bias, V, nullptr, ctrl, st);
+        else launch_transform64<2>(Y, m, f, Rinv, bias, V, nullptr, ctrl, st);
+        {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)solve64lr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                attr_set = true;
+            }
+            int64_t grid = (n + 3) / 4;
+            if (grid > 4096) grid = 4096;
+            WMF_LAUNCH("solve64lr_kernel", solve64lr_kernel, dim3((unsigned)grid), dim3(256), (size_t)4 * F64_LR_TEAM_DOUBLES * 8, st, V, Y, f, bias,
+                       indptr, indices, values, n, gbuf, fb_rows, fb_count, ctrl);
+        }
+        if (4 * f4 <= 256) launch_transform64<1>(gbuf, n, f, RinvT, 0, X, indptr, ctrl, st);
+        else launch_transform64<2>(gbuf, n, f, RinvT, 0, X, indptr, ctrl, st);
+        // ---- every other row (all of them when the low-rank path is off): the f x f system directly
         const int nblk = f64_blocks(f, true);
-#define S_(N, T, R) launch_solve64<N, T, R>(Y, f, bias, G, indptr, indices, values, n, X, fb_rows, fb_count, st)
+#define S_(N, T, R) launch_solve64<N, T, R>(Y, f, bias, G, indptr, indices, values, n, X, fb_rows, fb_count, ctrl, st)
         const bool waves = !(wmf_debug_flags & 67108864);       // debug flag 67108864 (timing experiments): workgroup teams at every width
         if (!waves && nblk <= 256) S_(1, 256, 16);
         else if (nblk <= 64) S_(1, 64, 8);            // one WAVE per row while a lane holds at most three blocks (f <= 68)
@@ -553,7 +901,7 @@ int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const 
         else if (nblk <= 1280) S_(5, 256, 16);
         else S_(9, 256, 16);
 #undef S_
-        // rows the Cholesky kernel could not take (count on the device; none as a rule)
+        // rows neither kernel could take (negative weights, not positive definite; count on the device; none as a rule)
         WMF_LAUNCH("solve64_lu_kernel", solve64_lu_kernel, dim3(WMF_F64_LU_GRID), dim3(256), 0, st, Y, f, bias, G, indptr, indices,
                    values, fb_rows, fb_count, X, slices, fail);
     }
