@@ -204,7 +204,8 @@ int wmf_confidence_transform_f64(double* values, int64_t nnz, double alpha, doub
  * are zero (:274-276, :296-298), and the float64 rows are stacked without a cast (np.stack, :246 / :261) -- so the
  * reference's `cores > 1` training continues on float64 factors (cores = 4 is the reference's default, :49-51).  This entry
  * point is that arithmetic on the device, without the whitening of the float32 path: Gramian in float64, then per row
- * the system accumulated and factored in registers, one workgroup per row (blocked Cholesky; a system that is not positive
+ * the system accumulated and factored in registers, one workgroup or wave per row (blocked Cholesky; rows with at most 32 stored
+ * entries through the whitened low-rank form -- a d x d system -- when they are at least a quarter of the rows; a system that is not positive
  * definite -- bias-adjusted weights below zero -- or not finite is redone by LU with partial pivoting, np.linalg.solve's
  * gesv); both agree with the float64 reference arithmetic to 1e-10.
  *   Y [m, f] float64 row-major (dense, no padding), values float64[nnz], X [n, f] float64 out, all on the device;

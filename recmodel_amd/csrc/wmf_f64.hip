@@ -559,13 +559,13 @@ __global__ __launch_bounds__(256) void solve64lr_kernel(const double* __restrict
                                                         const int32_t* __restrict__ ctrl) {
     extern __shared__ __attribute__((aligned(16))) double sm64[];
     if (ctrl[0] == 0) return;
-    constexpr int f4 = F64_LR_D / 4, LDY = F64_LR_D + 4;
+    constexpr int F4MAX = F64_LR_D / 4, LDY = F64_LR_D + 4;
     const int t = threadIdx.x & 63;
     const int tw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* ys = sm64 + (size_t)tw * F64_LR_TEAM_DOUBLES;
     double* ones = ys + F64_LR_RJ * LDY;
     double* panel = ones + F64_LR_RJ;
-    double* dbuf = panel + 2 * (f4 + 1) * 16;
+    double* dbuf = panel + 2 * (F4MAX + 1) * 16;
     double* yv = dbuf + 32;
     double* xs = yv + F64_LR_D;
     double* ev = xs + 4;
@@ -574,14 +574,17 @@ __global__ __launch_bounds__(256) void solve64lr_kernel(const double* __restrict
     int* ib = reinterpret_cast<int*>(cv + F64_LR_D);
     int bi[1], bj[1];
     bool on[1];
-    on[0] = t < f4 * (f4 + 1) / 2 + f4;
-    f64_decode(on[0] ? t : 0, f4, true, bi[0], bj[0]);
     if (t < F64_LR_RJ) ones[t] = 1.0;
     for (int i = t; i < F64_LR_RJ * 4; i += 64) ys[(i >> 2) * LDY + F64_LR_D + (i & 3)] = 0.0;     // the right-hand-side columns stay zero
     for (int64_t row = (int64_t)blockIdx.x * 4 + tw; row < n; row += (int64_t)gridDim.x * 4) {
         const int64_t lo = indptr[row], hi = indptr[row + 1];
         const int d = (int)min(hi - lo, (int64_t)(F64_LR_D + 1));
         if (d < 1 || d > F64_LR_D) continue;
+        // the system has f4 = ceil(d / 4) block rows (a 20-entry row: five block steps, not eight); its blocks are dealt to the lanes
+        // for this row (the staged columns d .. 31, among them the right-hand-side block's, are zero)
+        const int f4 = (d + 3) >> 2;
+        on[0] = t < f4 * (f4 + 1) / 2 + f4;
+        f64_decode(on[0] ? t : 0, f4, true, bi[0], bj[0]);
         f64_team_sync<64>();                                         // the previous row is done with the LDS vectors
         bool neg = false;
         if (t < F64_LR_D) {
