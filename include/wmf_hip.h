@@ -174,6 +174,12 @@ int wmf_hit_counts(const float* users, const float* items, int f, int ld, int bi
                    const int32_t* candidates, int32_t n_cand, const int32_t* slot,
                    const int32_t* topn, int32_t n_topn, int64_t* hits, void* stream);
 
+/* out[i, :] = in[rows[i], :] for i < n: the rows of a freshly solved factor block packed per destination rank, for the
+ * need-list exchange of the sharded engine (the parallelism that replaces the reference's Pool, wmf_model.py:245-249): each
+ * rank is sent only the rows its own half step reads.  in / out row-major with ld floats per row (ld a multiple of 4),
+ * rows int64[n] (indices into `in`; validated by the caller), all on the device.  Enqueues only. */
+int wmf_gather_rows(const float* in, int ld, const int64_t* rows, int64_t n, float* out, void* stream);
+
 /* g[u, :] = sum_j values[j] * V[indices[j], :]  (CSR x dense), the SpMM of the un-weighted
  * closed form wmf_model.py:85,88 in whitened coordinates. */
 int wmf_spmm_rows(const float* V, const int64_t* indptr, const int32_t* indices, const float* values,

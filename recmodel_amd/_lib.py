@@ -47,6 +47,7 @@ SIGNATURES = {
     "wmf_rank_topn_batch": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wmf_hit_counts": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "wmf_spmm_rows": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
+    "wmf_gather_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp]),
     "wmf_coo_to_csr_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "wmf_coo_to_csr": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "wmf_confidence_transform": (c_int, [c_vp, c_i64, c_dbl, c_dbl, c_int, c_vp]),

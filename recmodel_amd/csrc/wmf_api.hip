@@ -454,6 +454,12 @@ int wmf_hit_counts(const float* users, const float* items, int f, int ld, int bi
     return check_launch("wmf_hit_counts");
 }
 
+int wmf_gather_rows(const float* in, int ld, const int64_t* rows, int64_t n, float* out, void* stream) {
+    if (n < 0 || ld < 4 || (ld & 3) || (n > 0 && (!in || !rows || !out))) { wmf_set_error("wmf_gather_rows: null pointer or bad size"); return WMF_EINVAL; }
+    wmf_launch_gather_rows(in, ld, rows, n, out, (hipStream_t)stream);
+    return check_launch("wmf_gather_rows");
+}
+
 int wmf_spmm_rows(const float* V, const int64_t* indptr, const int32_t* indices, const float* values, int64_t n, int f,
                   int ld, float* g, void* stream) {
     int rc = check_shape(f, ld);

@@ -119,3 +119,22 @@ int wmf_launch_confidence(float* values, int64_t nnz, double alpha, double beta,
                (float)beta, mode);
     return 0;
 }
+
+// ---- rows of a factor block packed per destination (the need-list exchange): out[i] = in[rows[i]], 16 bytes per lane
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ in, int ld4, const int64_t* __restrict__ rows, int64_t n,
+                                                          float* __restrict__ out) {
+    const int64_t total = n * ld4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ld4, c = i - r * ld4;
+        reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(in)[rows[r] * ld4 + c];
+    }
+}
+
+int wmf_launch_gather_rows(const float* in, int ld, const int64_t* rows, int64_t n, float* out, hipStream_t st) {
+    if (n <= 0) return 0;
+    const int ld4 = ld >> 2;
+    int64_t grid = (n * ld4 + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    WMF_LAUNCH("gather_rows_kernel", gather_rows_kernel, dim3((unsigned)grid), dim3(256), 0, st, in, ld4, rows, n, out);
+    return 0;
+}

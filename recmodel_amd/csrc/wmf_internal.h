@@ -115,6 +115,7 @@ int64_t wmf_rank_batch_ws_bytes(int64_t nu, int64_t nc);
 int wmf_launch_rank_batch(const float* users, const float* items, int f, int ld, int bias, const int32_t* user_idx, int64_t nu,
                           const int32_t* cand, int64_t nc, int64_t topn, int32_t* out_pos, float* out_scores, void* ws,
                           int64_t ws_bytes, hipStream_t st);
+int wmf_launch_gather_rows(const float* in, int ld, const int64_t* rows, int64_t n, float* out, hipStream_t st);
 int wmf_launch_confidence(float* values, int64_t nnz, double alpha, double beta, int mode, hipStream_t st);
 // float64 half step of the cores > 1 variants (wmf_f64.hip)
 int64_t wmf_f64_ws_bytes(int f, int64_t m, int64_t n);

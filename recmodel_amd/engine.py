@@ -128,6 +128,12 @@ class HipKernels:
         _lib.check(self.lib.wmf_eliminate_rows(_ptr(partial), n, slots_per_row, f, ld, _ptr(g), _ptr(fail), _ptr(scratch),
                                                _stream()))
 
+    def gather_rows(self, src, rows):
+        """src[rows] as a new contiguous tensor (the rows of a solved block packed per destination: wmf_gather_rows)."""
+        out = torch.empty(rows.numel(), src.shape[1], dtype=src.dtype, device=src.device)
+        _lib.check(self.lib.wmf_gather_rows(_ptr(src), src.shape[1], _ptr(rows), rows.numel(), _ptr(out), _stream()))
+        return out
+
     def spmm_rows(self, V, indptr, indices, values, n, f, ld, g):
         _lib.check(self.lib.wmf_spmm_rows(_ptr(V), _ptr(indptr), _ptr(indices), _ptr(values), n, f, ld, _ptr(g), _stream()))
 
@@ -734,7 +740,9 @@ class AlsEngine:
         if self.sparse[side]:
             need = self.need[side]
             start, stop = self.chunk_range[side][c]
-            send = self.factors[side].index_select(0, need["send_idx"][c])          # packed per destination, rows ascending
+            # packed per destination, rows ascending (the library's copy kernel; the CPU stand-in of the tests indexes)
+            rows = need["send_idx"][c]
+            send = self.K.gather_rows(self.factors[side], rows) if hasattr(self.K, "gather_rows") else self.factors[side].index_select(0, rows)
             self._pending[side].append(self._all_to_all_rows(self.X[side][start:stop], send, need["recv_counts"][c],
                                                              need["send_counts"][c]))
             return
