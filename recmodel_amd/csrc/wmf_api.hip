@@ -569,7 +569,8 @@ int wmf_recompute_factors_f64_host(const double* Y_host, int64_t m, int f, int b
 int wmf_recompute_factors_host(const float* Y_host, int64_t m, int f, int bias, const int64_t* indptr,
                                const int32_t* indices, const float* values, int64_t n, double lambda, float* X_host) {
     if (!Y_host || !indptr || !X_host || m < 1 || n < 0 || f < 1 || f > WMF_MAX_F) {
-        wmf_set_error("wmf_recompute_factors_host: bad arguments");
+        wmf_set_error("wmf_recompute_factors_host: bad arguments (m=%lld, n=%lld, f=%d, Y=%p, indptr=%p, X=%p)", (long long)m, (long long)n, f,
+                      (const void*)Y_host, (const void*)indptr, (const void*)X_host);
         return WMF_EINVAL;
     }
     const int ld = wmf_ld_for(f);

@@ -225,8 +225,12 @@ __device__ __forceinline__ float wmf_qsum(float v) {
 // test fires there; a row that MIXES weights of 1e4 and more with ordinary ones (alpha * count, 'linear') goes to the pivoted LU
 // kernel instead, which is slower and as accurate as float32 allows (measured on MI355X, tests/scale/diag_weights_mixed.py:
 // 1e-3 at cond 1e4 where the tile-inverse path gave 0.1 .. 0.5).
+#ifndef WMF_PIVOT_CAP
 #define WMF_PIVOT_CAP 256.f
+#endif
+#ifndef WMF_PIVOT_SPREAD
 #define WMF_PIVOT_SPREAD 8.f
+#endif
 template <int K, bool LDS, bool CHECK, bool CAP = false>
 __device__ __forceinline__ void gj_inv_step(f32x4& a, float& dsc, const int (&baddr)[4], int r, int q, bool& ok, float& plo, float& phi) {
     constexpr int kq = K >> 2, kr = K & 3;

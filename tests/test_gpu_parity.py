@@ -793,6 +793,57 @@ def test_very_heavy_rows_are_split_into_segments(WMF, k, bias):
     assert np.array_equal(got, step_g(model.items, C, 0.1))          # fixed combination order: bitwise reproducible
 
 
+@pytest.mark.parametrize("f,bias", [(193, True), (209, True), (225, True), (241, True), (257, True), (225, False), (240, False)])
+def test_wide_rows_under_full_occupancy_are_right_and_reproducible(WMF, f, bias):
+    """144 < f <= 257 with EVERY row heavy (30 .. 700 entries), more rows than the chip holds workgroups: all resident
+    workgroups of the four-waves-per-row kernel are busy at once.  Round 3's fuzzing found the border widths with 13 .. 15 blocks
+    (f = 209, 225, 241) wrong and different from run to run in exactly this situation -- two such workgroups on one CU -- while
+    the small ragged matrices of the other tests never filled a CU; wmf_rowsplit.hip now keeps those three to one workgroup per
+    CU.  Two runs must agree bit for bit, and 120 sampled rows must match the float64 oracle."""
+    rng = np.random.default_rng(f)
+    n, m_items = 1200, 700
+    k = f - int(bias)
+    deg = rng.integers(30, 700, n)
+    indptr = np.concatenate([[0], np.cumsum(deg)])
+    indices = np.concatenate([np.sort(rng.choice(m_items, d, replace=False)) for d in deg]).astype(np.int32)
+    data = (10 * np.log(1 + rng.integers(1, 8, indptr[-1]))).astype(np.float32)
+    C = sp.csr_matrix((data, indices, indptr), shape=(n, m_items))
+    model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=bias)
+    Y = model.items.copy()
+    if bias:
+        Y[:, 0] *= 0.5
+    step_g = model.recompute_factors_bias if bias else model.recompute_factors
+    got = step_g(Y, C, 0.1)
+    again = step_g(Y, C, 0.1)
+    assert np.array_equal(got, again), int((np.abs(got - again).max(axis=1) > 0).sum())
+    rows = rng.choice(n, 120, replace=False)
+    sub = sp.csr_matrix((np.concatenate([data[indptr[r]: indptr[r + 1]] for r in rows]).astype(np.float64),
+                         np.concatenate([indices[indptr[r]: indptr[r + 1]] for r in rows]),
+                         np.concatenate([[0], np.cumsum(deg[rows])])), shape=(len(rows), m_items))
+    want = (orc.recompute_factors_bias if bias else orc.recompute_factors)(Y, sub, 0.1, out_dtype="float64")
+    rel, _ = worst_row(got[rows], want)
+    record_error(f"wide_rows_full_occupancy[f={f},bias={int(bias)}]", worst_row=rel, fro=fro(got[rows], want))
+    assert fro(got[rows], want) <= WIDE_FRO and rel <= WIDE_ROW, (fro(got[rows], want), rel)
+
+
+def test_wide_rows_reproducible_at_every_block_count(WMF):
+    """Two runs of the four-waves-per-row kernel must agree bit for bit at every block count 10 .. 16, border or not, with all
+    resident workgroups busy (the check that would have caught round 3's f = 209 / 225 / 241 finding in round 2)."""
+    rng = np.random.default_rng(77)
+    n, m_items = 1100, 600
+    deg = rng.integers(33, 600, n)
+    indptr = np.concatenate([[0], np.cumsum(deg)])
+    indices = np.concatenate([np.sort(rng.choice(m_items, d, replace=False)) for d in deg]).astype(np.int32)
+    data = (10 * np.log(1 + rng.integers(1, 8, indptr[-1]))).astype(np.float32)
+    C = sp.csr_matrix((data, indices, indptr), shape=(n, m_items))
+    for f in (145, 160, 161, 176, 177, 192, 193, 208, 209, 224, 225, 240, 241, 256, 257):
+        model = WMF(num_items=m_items, num_users=n, dim=f, gamma=0.1, weighted=True, bias=False)
+        got = model.recompute_factors(model.items, C, 0.1)
+        again = model.recompute_factors(model.items, C, 0.1)
+        assert np.isfinite(got).all(), f
+        assert np.array_equal(got, again), (f, int((np.abs(got - again).max(axis=1) > 0).sum()))
+
+
 # ------------------------------------------------------------------ degenerate shapes
 @pytest.mark.parametrize("bias", [False, True])
 def test_degenerate_shapes(WMF, bias):
