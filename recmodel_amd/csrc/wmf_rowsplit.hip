@@ -189,6 +189,12 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
             for (int j = 0; j < 8; ++j) {
                 const float x = e == 0 ? pre8[j].x : (e == 1 ? pre8[j].y : (e == 2 ? pre8[j].z : pre8[j].w));
                 yreg[e] += x * ppre8[j];
+#ifndef RS_Y_PAIRED
+                // Keeps hipcc's SLP vectoriser from pairing y with b in one v_pk_fma_f32 chain: with that pairing the BORDER kernels
+                // at NFB = 13 .. 15 lost y's reproducibility at two workgroups per CU (round-3 note in launch_rowsplit_f).
+                // RS_Y_PAIRED (lab, with RS_NO_ALONE and without -fno-slp-vectorize) brings the failure back.
+                asm volatile("" : "+v"(yreg[e]));
+#endif
                 if constexpr (BORDER) breg[e] += x * bw[j];
                 {
 #pragma clang fp contract(off)
@@ -641,11 +647,15 @@ static void launch_rowsplit_f(const int32_t* rows, int64_t count, const float* V
     // a CU).  What was established on MI355X: only the right-hand side y goes wrong, already at the end of the accumulation
     // (b, c and the tiles, summed by the same packed instructions from the same operands, stay exact); the amount of LDS, its
     // layout, wait states in front of the asm blocks and vector instead of scalar loads change nothing; the same object
-    // code is right at one workgroup per CU; and the file compiled with -fno-slp-vectorize (no v_pk_*_f32) is right at two.
+    // code is right at one workgroup per CU; the file compiled with -fno-slp-vectorize (no v_pk_*_f32) is right at two; and so
+    // is the default build once an empty asm on yreg[e] keeps the vectoriser from pairing y with b in stage32's v_pk_fma_f32
+    // chain (lo half y, hi half b, the hi half of the multiplier pair written by a v_mul_f32 one or two instructions ahead).
+    // A stand-alone probe of that instruction pattern (tools/lab/pk_hazard_probe.hip, 2 and 8 waves per SIMD, low and high
+    // registers) does NOT fail, so the pattern alone is not the mechanism.
     // Every other width 145 .. 257, with and without the border, is reproducible and exact either way (800-case sweep).
-    // Two independent guards, until the mechanism is known: the Makefile builds this file with -fno-slp-vectorize (measured
-    // neutral on cfg5s: 56.2 against 56.9 ms per iteration), and these three widths launch with at least 82 KB of LDS, so
-    // that a CU holds one of their workgroups.  RS_NO_ALONE (lab) removes the second guard.
+    // Three independent guards, until the mechanism is known: that empty asm in stage32; the Makefile builds this file with
+    // -fno-slp-vectorize (measured neutral on cfg5s: 56.2 against 56.9 ms per iteration); and these three widths launch with at
+    // least 82 KB of LDS, so that a CU holds one of their workgroups.  RS_NO_ALONE (lab) removes the last one.
 #ifdef RS_NO_ALONE
     constexpr bool ALONE = false;
 #else

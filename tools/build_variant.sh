@@ -8,6 +8,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 c=$root/recmodel_amd/csrc
 mkdir -p $root/build/variants
 make -s -C $c
+[ "$src" = "wmf_rowsplit.hip" ] && [ -z "$RS_KEEP_SLP" ] && extra="$extra -fno-slp-vectorize"      # as the Makefile does (RS_KEEP_SLP=1: lab)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wall -Wno-unused-function $extra -c $c/$src -o $root/build/variants/$name.o
 if [ "$src" = "wmf_directl.hip" ]; then python3 $root/tools/check_inflight_regs.py $c/$src $extra; fi
 objs=""
