@@ -22,6 +22,7 @@ the HBM byte count of the same kernel in the newest committed rocprofv3 --pmc pr
 import argparse
 import glob
 import json
+import re
 import os
 import sys
 import time
@@ -162,6 +163,38 @@ def kernel_work(name, csr, eng, side):
     return None
 
 
+F16_MFMA_PEAK_TF = 2500.0   # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md): what the split-f16 tile products run on
+HEAVY_T = 4096              # wmf_internal.h WMF_HEAVY_T: rows above it are accumulated in segments (MODE 1 / 2)
+
+
+def mfma_issue_line(name, csr, avg_ms):
+    """The second roofline of the split-f16 heavy-row kernels: the v_mfma_f32_16x16x32_f16 instructions they ISSUE (three per
+    upper-triangle tile and 32-entry chunk: Al.Bh + Ah.Bl + Ah.Bh; two per tile product of the block elimination, hi | lo packed
+    into K = 32) at 16 384 flop each against the dense f16 matrix peak.  Where this floor is above the HBM floor (k = 256: 9 ms
+    against 5 ms per cfg5s item launch) the matrix pipe, not HBM, is what bounds the kernel as designed."""
+    m = re.match(r"solve_(directl|rowsplit)_kernel<(\d+), (true|false), (true|false)(?:, \d+)?, (\d)>", name)
+    if not m or m.group(4) != "true":
+        return None
+    nfb, mode = int(m.group(2)), int(m.group(5))
+    tiles = nfb * (nfb + 1) // 2
+    elim = nfb * (nfb - 1) + (nfb - 1) * nfb * (nfb + 1) // 3
+    deg = csr.indptr[1:] - csr.indptr[:-1]
+    normal, heavy = deg[(deg > 32) & (deg <= HEAVY_T)], deg[deg > HEAVY_T]
+    if mode == 0:
+        n_mfma = 3 * tiles * int(((normal + 31) // 32).sum().item()) + elim * int(normal.numel())
+    elif mode == 1:
+        n_mfma = 3 * tiles * int(((heavy + 31) // 32).sum().item())
+    else:
+        n_mfma = elim * int(heavy.numel())
+    flops = 16384.0 * n_mfma
+    if flops <= 0 or avg_ms <= 0:
+        return None
+    ach = flops / (avg_ms / 1e3) / 1e12
+    return {"bound": "mfma", "issued_mfma_per_launch": n_mfma, "issued_tflop_per_launch": flops / 1e12, "achieved": ach,
+            "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TF, "floor_ms": flops / (F16_MFMA_PEAK_TF * 1e12) * 1e3,
+            "what": "v_mfma_f32_16x16x32_f16 issued by the split-f16 accumulation (3 per tile and 32 entries) and elimination (2 per tile product)"}
+
+
 def transform_work(eng, rows):
     return "hbm", 8.0 * eng.f * rows                                         # one row read, one row written
 
@@ -293,6 +326,11 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu, zipf=
             entry.update({"bound": bound, "algorithmic_units_per_launch": float(units), "achieved": ach, "peak": peak,
                           "unit": unit, "frac": ach / peak,
                           "traffic": traffic_of(traffic, name, side, name in names_both)})
+            if bound == "hbm":
+                line = mfma_issue_line(name, eng.csr[side], ms / launches)
+                if line is not None:
+                    entry["hbm_floor_ms"] = units / (HBM_PEAK_GBS * 1e9) * 1e3
+                    entry["mfma_issue"] = line
         kernels.append(entry)
     cand = [e for e in kernels if "frac" in e]
     roofline = None
@@ -304,6 +342,9 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu, zipf=
                                        "2 x FETCH + WRITE; not measured in this run") if dom["traffic"] is not None else None,
                     "algorithmic_units_per_launch": dom["algorithmic_units_per_launch"], "avg_launch_ms": dom["avg_ms"],
                     "launches": dom["launches"], "share_of_step": dom["total_ms"] / (elapsed * 1e3)}
+        if "mfma_issue" in dom:
+            roofline["hbm_floor_ms"] = dom["hbm_floor_ms"]
+            roofline["mfma_issue"] = dom["mfma_issue"]
     # the north star's named target: the per-user solve (every row kernel of the users half step together)
     half = {}
     for s in SIDES:

@@ -342,7 +342,10 @@ class WMF(RecModel):
                 if count_improvement >= stopping_rounds:
                     break
             self._pull(eng)
-            self.users, self.items = self.users.astype(np.float64), self.items.astype(np.float64)
+            # (the reference's dense-times-sparse products, :85 / :88, take NumPy's result type of the model dtype and the
+            # utility matrix's: float64 for SciPy's default float64 matrices, float32 for float32 ones)
+            out_dt = np.result_type(np.dtype(self.dtype), utility_mat.dtype)
+            self.users, self.items = self.users.astype(out_dt), self.items.astype(out_dt)
             self._freeze()
             if verbose > 0:
                 print("Training was completed.")

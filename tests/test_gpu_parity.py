@@ -200,6 +200,21 @@ def test_rank_select_with_ties_and_extremes():
     assert r[0] == 5 and r[-1] == 6
 
 
+def test_unweighted_branch_dtype_follows_the_utility_matrix(WMF):
+    """wmf_model.py:85 / :88 are dense-times-sparse products: NumPy's result type of the model dtype (float32) and the utility
+    matrix's -- float64 factors for SciPy's default float64 matrices (the golden), float32 ones for a float32 matrix (found by
+    tests/scale/fuzz_train.py in round 3: the class returned float64 there)."""
+    rng = np.random.default_rng(3)
+    util = sp.random(90, 70, density=0.2, format="csr", random_state=5, data_rvs=lambda s: rng.integers(1, 5, s).astype(np.float64))
+    for dt in (np.float32, np.float64, np.int64):
+        u = util.astype(dt)
+        m = WMF(num_items=70, num_users=90, dim=8, gamma=0.1, weighted=False, bias=False)
+        m.train(utility_mat=u, iterations=2, eval_mat=u.astype(np.float32))
+        _, _, wu, wi = orc.train(70, 90, 8, 0.1, u, 2, u.astype(np.float32), weighted=False)
+        assert m.users.dtype == wu.dtype and m.items.dtype == wi.dtype, (dt, m.users.dtype, wu.dtype)
+        assert fro(m.users, wu) <= TRAIN_FRO and fro(m.items, wi) <= TRAIN_FRO
+
+
 def test_unweighted_branch_matches_reference_golden(WMF):
     g = load_golden("train_unweighted.npz")
     util = csr_from(g, "util")
