@@ -171,9 +171,6 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
         }
     };
     auto stage32 = [&]() {
-#ifdef RS_WAIT_A
-        __builtin_amdgcn_s_waitcnt(0);                           // lab: nothing in flight when the accumulation of y / b starts
-#endif
         float sw[8], bw[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -181,9 +178,6 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
             bw[j] = 0.f;
             if constexpr (BORDER) {
                 bw[j] = bfpre8[j] * wpre8[j];
-#ifdef RS_BW_EARLY
-                asm volatile("" : "+v"(bw[j]));                  // lab: the product exists here, long before the packed chain reads it
-#endif
                 creg += bfpre8[j] * bw[j];
                 ereg += bfpre8[j] * ppre8[j];
             }
@@ -237,9 +231,6 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
         int64_t lon = 0;
         if (itn < count) item(itn, un, lon, dn);
 
-#ifdef RS_WAIT_B
-        __builtin_amdgcn_s_waitcnt(0);                           // lab: nothing in flight when a row starts
-#endif
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -258,9 +249,6 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
                 __syncthreads();
                 if (c + 1 < nchunks32) load_chunk32(lo, d, 32 * (c + 1));         // flies during this chunk's MFMAs
                 else if (itn < count && MODE != 2) load_chunk32(lon, dn, 0);     // ... or during the elimination
-#ifdef RS_WAIT_C
-                __builtin_amdgcn_s_waitcnt(0);                   // lab: the next chunk's loads have landed before the tile products start
-#endif
                 rs_f16x8 Ah[4], Al[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -664,8 +652,8 @@ static void launch_rowsplit_f(const int32_t* rows, int64_t count, const float* V
     // chain (lo half y, hi half b, the hi half of the multiplier pair written by a v_mul_f32 one or two instructions ahead).
     // A stand-alone probe of that instruction pattern (tools/lab/pk_hazard_probe.hip, 2 and 8 waves per SIMD, low and high
     // registers) does NOT fail, so the pattern alone is not the mechanism.  With the pairing left in (RS_Y_PAIRED, RS_KEEP_SLP=1)
-    // neither s_waitcnt 0 -- every counter -- at the start of stage32, of a row, or in front of the tile products (RS_WAIT_A / B / C:
-    // nothing is in flight that could land late), nor forming b.w eight instructions ahead of the chain (RS_BW_EARLY) changes it.
+    // neither s_waitcnt 0 -- every counter -- at the start of stage32, of a row, or in front of the tile products (nothing is in flight
+    // that could land late), nor forming b.w eight instructions ahead of the chain changes it.
     // Every other width 145 .. 257, with and without the border, is reproducible and exact either way (800-case sweep).
     // Three independent guards, until the mechanism is known: that empty asm in stage32; the Makefile builds this file with
     // -fno-slp-vectorize (measured neutral on cfg5s: 56.2 against 56.9 ms per iteration); and these three widths launch with at
