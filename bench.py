@@ -146,12 +146,20 @@ def kernel_work(name, csr, eng, side):
         return "hbm", (nnz[0] - csr.nnz8) * ent_b + (rows[0] - csr.rows8) * row_b
     if name.startswith("solve_low_kernel"):
         return "hbm", nnz[1] * ent_b + rows[1] * row_b
-    if name.startswith("solve_directl_kernel") or name.startswith("solve_directw_kernel") and ", 0," in name:
-        return "hbm", (nnz[2] - csr.nnz_split) * ent_b + (rows[2] - csr.rows_split) * row_b
-    if name.startswith("solve_directw_kernel") and ", 1," in name:          # segments of the split rows: the gathers
-        return "hbm", csr.nnz_split * ent_b
-    if name.startswith("solve_rowsplit_kernel") or name.startswith("solve_wide_kernel"):
-        return "hbm", nnz[3] * ent_b + rows[3] * row_b
+    m = re.match(r"solve_(directl|directw|rowsplit|wide)_kernel<([^>]*)>", name)
+    if m:
+        # MODE of the launch: 0 = whole rows (everything of the bin that is not split), 1 = the 2048-entry segments of the
+        # rows above 4096 entries (their gathers; the written partial systems are not algorithmic bytes), 2 = the elimination
+        # of the summed segments (reads partial systems only: no HBM model, no frac)
+        targs = [a.strip() for a in m.group(2).split(",")]
+        kind = m.group(1)
+        mode = int(targs[1]) if kind == "directw" else (int(targs[-1]) if kind in ("directl", "rowsplit") else 0)
+        b = 2 if kind in ("directl", "directw") else 3
+        if mode == 0:
+            return "hbm", (nnz[b] - csr.nnz_split) * ent_b + (rows[b] - csr.rows_split) * row_b
+        if mode == 1:
+            return "hbm", csr.nnz_split * ent_b
+        return None
     if name.startswith("gram") and "reduce" not in name:
         # one pass over the fixed side (B_gram = 4 m f).  The f32-MFMA Gramian (gram_kernel) is priced against
         # the exact-f32 matrix peak; the split-bf16 one (gram6_kernel, f = 97 .. 144) runs its products at the bf16 rate and
@@ -302,7 +310,9 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu, zipf=
 
     # ---- per-kernel table and rooflines (this rank's launches) --------------------------------
     f = eng.f
-    traffic, traffic_src = traffic_table(cfg_name)
+    # counted traffic exists only for the workloads that were profiled (profiles/rNN_<config>_traffic.json are runs of the
+    # UNIFORM matrices): a skewed variant has no profile of its own and reports null
+    traffic, traffic_src = traffic_table(cfg_name) if not zipf else (None, None)
     names_both = {n for n, t, *_ in table if t == 0} & {n for n, t, *_ in table if t == 1}
     kernels, solve_ms = [], {s: 0.0 for s in SIDES}
     for name, tag, ms, launches, lo, hi in sorted(table, key=lambda e: -e[2]):
@@ -374,6 +384,9 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu, zipf=
         "config": {"workload": f"{cfg_name}: WMF k={k}{'+bias' if bias else ''}, {n_users}x{n_items} CSR, "
                                f"{nnz} nnz, alpha-log confidence, gamma={gamma}, zipf_a={zipf}",
                    "n_users": n_users, "n_items": n_items, "nnz": nnz, "k": k, "bias": bias,
+                   "exchange": {s_: (("reduce" if eng.reduce[s_] else "need-list" if eng.sparse[s_] else "all-gather")
+                                     + ("+pipelined" if eng.pipe[s_] else "")) + f" x{len(eng.chunk_bounds[s_])}"
+                                for s_ in SIDES} if world > 1 or eng.exchange else None,
                    "sharding": f"users+items dealt by cost (nnz f^2 + f^3) over {world} GPU(s), every rank loads 1/{world} of the user "
                                f"rows; exchange users: "
                                f"{'reduce-scatter of partial systems' if eng.reduce['users'] else ('need-list all-to-all (%.0f %% of the rows per rank)' % (100 * eng.need['users']['needed_fraction']) if eng.sparse['users'] else 'all-gather')} in "
@@ -467,6 +480,74 @@ def float64_path(cfg_name, dev, lib, iters=2):
             "what": "wmf_half_step_f64 (users + items): the reference's cores > 1 variants, float64 end to end"}
 
 
+def _r(x, digits=4):
+    """Numbers of the compact line: ``digits`` significant figures."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _side(h):
+    return {"ms": _r(h["solve_kernels_ms"]), "algorithmic_GB": _r(h["algorithmic_bytes"] / 1e9), "achieved": _r(h["achieved"]),
+            "frac": _r(h["frac"])} if h and h.get("frac") is not None else None
+
+
+def compact_roofline(r):
+    if not r:
+        return None
+    out = {k: _r(r[k], 6) for k in ("kernel", "half_step", "bound", "achieved", "peak", "unit", "frac", "traffic") if k in r}
+    out["traffic_source"] = (r.get("traffic_source") or "")[:60] or None
+    out.update({"algorithmic_units_per_launch": _r(r["algorithmic_units_per_launch"], 6), "avg_launch_ms": _r(r["avg_launch_ms"], 6),
+                "launches": r["launches"], "share_of_step": _r(r["share_of_step"])})
+    if r.get("paths"):
+        out["paths"] = r["paths"]
+    out["user_solve"], out["item_solve"] = _side(r.get("user_solve")), _side(r.get("item_solve"))
+    return out
+
+
+def compact_line(full, detail_path):
+    """The one stdout line: the contract keys, config, roofline (dominant kernel + the two half steps' solves), cpu_baseline,
+    ranks and one small object per further workload.  Everything else is in ``detail_path`` / on stderr."""
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _r(line["value"], 6), _r(line["ms_per_step"], 6)
+    c = full["config"]
+    line["config"] = {"workload": c["workload"], "n_users": c["n_users"], "n_items": c["n_items"], "nnz": c["nnz"], "k": c["k"],
+                      "bias": c["bias"], "exchange": c["exchange"]}
+    line["nnz_per_s"], line["epoch_hbm_frac"] = _r(full["nnz_per_s"]), _r(full["epoch_hbm_frac"])
+    line["roofline"] = compact_roofline(full.get("roofline"))
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        line["cpu_baseline"] = {"value": _r(cpu["value"]), "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+                                "sample": cpu["sample"][:200], "host_cpus": cpu.get("host_cpus")}
+        ac = cpu.get("all_cores") or {}
+        line["cpu_baseline"]["all_cores"] = ({"value": _r(ac["value"]), "cores": ac["cores"], "kind": ac["kind"],
+                                              "sample": ac["sample"][:120]} if "value" in ac else ac)
+    else:
+        line["cpu_baseline"] = None
+    rk = full.get("ranks") or {}
+    line["ranks"] = {"world_size": rk.get("world_size"), "backend": rk.get("backend"),
+                     "bytes_sent_per_half_step": rk.get("bytes_this_rank_sends_per_half_step")}
+    hb = full.get("host_boundary")
+    if hb:
+        line["host_boundary_rows_per_s"] = _r(hb["value"])
+    if full.get("also"):
+        line["also"] = {}
+        for name, r in full["also"].items():
+            if "ms_per_step" not in r:                       # float64_path or an error record
+                line["also"][name] = {k: _r(v) for k, v in r.items() if k in ("ms_per_iteration", "vs_float32_path", "error", "cfg3_ms_per_iteration")}
+                continue
+            ro = r.get("roofline") or {}
+            line["also"][name] = {"ms_per_step": _r(r["ms_per_step"]), "value": _r(r["value"]), "kernel": ro.get("kernel"),
+                                  "kernel_ms": _r(ro.get("avg_launch_ms")), "frac": _r(ro.get("frac")),
+                                  "user_solve_frac": _r((ro.get("user_solve") or {}).get("frac")),
+                                  "item_solve_frac": _r((ro.get("item_solve") or {}).get("frac")),
+                                  "paths": ro.get("paths"),
+                                  "cpu_baseline": _r((r.get("cpu_baseline") or {}).get("value"))}
+    line["detail"] = detail_path
+    return line
+
+
 def main():
     args = parse()
     # stdout carries exactly one line, the JSON result: RCCL prints a version banner to stdout when a communicator is
@@ -549,8 +630,24 @@ def main():
     out["cpu_baseline"] = cpu
     out["also"] = also
     if rank == 0:
+        # The FULL record (per-kernel tables of every workload, row bins, host boundary, notes) goes to a file and to stderr;
+        # stdout carries ONE compact line (a few KB) that the driver's record can hold whole.
+        detail_path = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        try:
+            os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+            with open(detail_path, "w") as fh:
+                json.dump(out, fh)
+        except OSError as exc:
+            detail_path = f"(not written: {exc})"
+        for tag, r in [(args.config, out)] + [(n, r) for n, r in (also or {}).items() if "kernels" in r]:
+            print(f"[bench] {tag}: {r['ms_per_step']:.3f} ms per iteration", file=sys.stderr)
+            for e in r["kernels"][:8]:
+                print(f"[bench]   {e['kernel']:<52} {e['half_step']:<6} avg {e['avg_ms']:8.4f} ms  frac "
+                      f"{e.get('frac', float('nan')):.3f}", file=sys.stderr)
+        print(f"[bench] full record: {detail_path}", file=sys.stderr, flush=True)
+        line = compact_line(out, os.path.relpath(detail_path, ROOT) if not detail_path.startswith("(") else detail_path)
         sys.stdout.flush()
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if world > 1 or force_exchange:
         torch.distributed.destroy_process_group()
 

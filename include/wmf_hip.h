@@ -108,8 +108,16 @@ void wmf_plan_destroy(wmf_plan* p);
 /* Rows and stored entries the plan routes to each kernel family: out12[b] = rows, out12[4+b] =
  * stored entries, for b = 0: <=16 entries, 1: 17..32, 2: one wave per row (f <= 144), 3: four waves per row (f > 144);
  * out12[8], out12[9] = rows and entries of bin 0 with at most 8 entries (two rows share a wave);
- * out12[10], out12[11] = rows and entries of bin 2 with more than 4096 entries (split over several waves). */
-int  wmf_plan_stats(const wmf_plan* p, int64_t* out12);
+ * out[10], out[11] = rows and entries of bin 2 / 3 with more than 4096 entries (split over several waves);
+ * out[12], out[13] = rows and entries of bin 2 / 3 that are candidates of the matrix-free iteration kernel (33 .. a
+ * width-dependent number of entries; round 4).  The array has 14 elements. */
+int  wmf_plan_stats(const wmf_plan* p, int64_t* out14);
+/* What became of those candidates in the solves since the last call: out4 = { rows solved by the iteration, rows handed
+ * back to the elimination kernels (bound on the row's operator too weak, or no convergence), applications of the row
+ * operator in total, rows solved by the Chebyshev rather than the Neumann recurrence }.  Data dependent: a row is solved
+ * by a truncated polynomial in E = V_u^T D V_u only when tr E bounds it away from the direct method's cost
+ * (csrc/wmf_iter.hip).  Synchronises the device and clears the counters. */
+int  wmf_plan_iter_stats(wmf_plan* p, int64_t* out4);
 
 /* The per-row normal-equation solve in whitened coordinates, for every row of the CSR:
  *   g_u = (I + V_u^T D_u V_u)^-1 V_u^T (w_u + 1),   V_u = V[idx_u], D_u = diag(w_u)

@@ -34,6 +34,7 @@ SIGNATURES = {
     "wmf_plan_create": (c_int, [c_vp, c_i64, c_int, c_int, ctypes.POINTER(c_vp)]),
     "wmf_plan_destroy": (None, [c_vp]),
     "wmf_plan_stats": (c_int, [c_vp, c_vp]),
+    "wmf_plan_iter_stats": (c_int, [c_vp, c_vp]),
     "wmf_solve_rows": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     "wmf_eval_workspace_bytes": (c_i64, []),
     "wmf_eval_sqerr": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),

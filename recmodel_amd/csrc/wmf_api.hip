@@ -230,13 +230,22 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, int bias, wmf_plan*
         const int64_t d = indptr[r + 1] - indptr[r];
         if (d <= 8) { order[(size_t)fill[WMF_BIN_LOW16]++] = (int32_t)r; p->count8++; p->nnz8 += d; }
     }
+    // (round 4) ... and, first of all, the rows short enough for the matrix-free iteration kernel (wmf_iter.hip): at most
+    // wmf_iter_dmax entries -- what a workgroup of that kernel keeps in registers at this width
+    const bool split_layout = bias && wmf_split_layout(f, wmf_ld_for(f));
+    const int64_t iter_dmax = wmf_iter_dmax(f, wmf_ld_for(f), split_layout ? 1 : 0);
+    p->iter_dmax = (int)iter_dmax;
+    std::vector<int32_t> longer;
     for (int64_t r = 0; r < n; ++r) {
         const int64_t d = indptr[r + 1] - indptr[r];
         const int b = bin_of(d, f);
         if (b == WMF_BIN_LOW16 && d <= 8) continue;
         if (b == hb && can_split && d > WMF_HEAVY_T) { heavy.push_back((int32_t)r); continue; }
+        if (b == hb && d > iter_dmax) { longer.push_back((int32_t)r); continue; }
+        if (b == hb) { p->iter_count++; p->iter_nnz += d; }
         order[(size_t)fill[b]++] = (int32_t)r;
     }
+    for (int32_t r : longer) order[(size_t)fill[hb]++] = r;
     std::vector<int64_t> seg_lo;
     std::vector<int32_t> seg_d, seg_first(1, 0);
     for (int32_t r : heavy) {
@@ -266,6 +275,9 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, int bias, wmf_plan*
     p->split = bias && wmf_split_layout(f, wmf_ld_for(f));
     if (e == hipSuccess && bias && !p->split && nnz_all > 0) e = hipMalloc((void**)&p->w_eff, (size_t)nnz_all * sizeof(float));
     if (e == hipSuccess && f > 144) e = hipMalloc((void**)&p->wide_ws, wmf_wide_lu_workspace_bytes(f));
+    if (e == hipSuccess && p->iter_count > 0) e = hipMalloc((void**)&p->iter_bounce_rows, (size_t)p->iter_count * sizeof(int32_t));
+    if (e == hipSuccess && p->iter_count > 0) e = hipMalloc((void**)&p->iter_stats, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess && p->iter_count > 0) e = hipMemset(p->iter_stats, 0, 4 * sizeof(unsigned long long));
     if (e == hipSuccess && p->heavy_count > 0) {
         const int64_t nfb = (f + 15) / 16, nt = nfb * (nfb + 1) / 2 + nfb;
         const int64_t pfloats = wmf_direct_supported(f) ? nt * 256 : wmf_rowsplit_partial_floats(f);
@@ -294,6 +306,8 @@ void wmf_plan_destroy(wmf_plan* p) {
     if (p->fallback_count) (void)hipFree(p->fallback_count);
     if (p->w_eff) (void)hipFree(p->w_eff);
     if (p->wide_ws) (void)hipFree(p->wide_ws);
+    if (p->iter_bounce_rows) (void)hipFree(p->iter_bounce_rows);
+    if (p->iter_stats) (void)hipFree(p->iter_stats);
     if (p->seg_lo) (void)hipFree(p->seg_lo);
     if (p->seg_d) (void)hipFree(p->seg_d);
     if (p->seg_first) (void)hipFree(p->seg_first);
@@ -301,11 +315,28 @@ void wmf_plan_destroy(wmf_plan* p) {
     delete p;
 }
 
-int wmf_plan_stats(const wmf_plan* p, int64_t* out8 /* int64[12] */) {
+int wmf_plan_stats(const wmf_plan* p, int64_t* out8 /* int64[14] */) {
     if (!p || !out8) { wmf_set_error("wmf_plan_stats: null"); return WMF_EINVAL; }
     for (int b = 0; b < WMF_NBINS; ++b) { out8[b] = p->count[b]; out8[WMF_NBINS + b] = p->nnz[b]; }
     out8[8] = p->count8; out8[9] = p->nnz8;
     out8[10] = p->heavy_count; out8[11] = p->heavy_nnz;
+    out8[12] = p->iter_count; out8[13] = p->iter_nnz;
+    return WMF_OK;
+}
+
+// What the iteration kernel (wmf_iter.hip) did with its candidates since the last call: rows solved, rows handed back to the
+// elimination kernels, applications of the row operator in total, rows solved by the Chebyshev (rather than Neumann) recurrence.
+// Synchronises the device; clears the counters.
+int wmf_plan_iter_stats(wmf_plan* p, int64_t* out4) {
+    if (!p || !out4) { wmf_set_error("wmf_plan_iter_stats: null"); return WMF_EINVAL; }
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    if (!p->iter_stats) return WMF_OK;
+    unsigned long long h[4];
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(h, p->iter_stats, sizeof(h), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemset(p->iter_stats, 0, sizeof(h));
+    if (e != hipSuccess) { wmf_set_error("wmf_plan_iter_stats: %s", hipGetErrorString(e)); return WMF_EHIP; }
+    for (int i = 0; i < 4; ++i) out4[i] = (int64_t)h[i];
     return WMF_OK;
 }
 

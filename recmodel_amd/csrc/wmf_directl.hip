@@ -111,8 +111,10 @@ __global__ __launch_bounds__(64, (NFB <= 4 || GE == 8) ? 2 : 1) void solve_direc
                                                               const float* __restrict__ vals, int f, int ld, float* __restrict__ g,
                                                               int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int dbg,
                                                               const int64_t* __restrict__ seg_lo, const int32_t* __restrict__ seg_d,
-                                                              float* __restrict__ partial) {
+                                                              float* __restrict__ partial, const int32_t* __restrict__ count_dev) {
     static_assert(MODE == 0 || X6, "segments: split-f16 path only");
+    // count_dev != NULL: the number of rows is on the device (the list of rows the iteration kernel bounced, wmf_iter.hip)
+    if (count_dev) count = *count_dev;
     // side != NULL (BORDER only): the split layout of a bias model's fixed side (wmf_internal.h) -- V holds packed body rows
     // of f - 1 = 16 NFB floats (exactly the RB bytes a ring row takes), side the {last feature, bias} pairs
     const bool split = BORDER && side != nullptr;
@@ -565,9 +567,13 @@ int wmf_directl_supported(int f, int ld) {
     return (f == 128 && ld == 128) || (f == 129 && ld == 132) || (f == 64 && ld == 64) || (f == 65 && ld == 68);
 }
 
+// the launch over the rows the iteration kernel bounced is a separate line of the per-kernel timing table
+static const char* dl_name(const char* base, bool bounced) { return bounced ? wmf_kname("%s [bounced]", base) : base; }
+
 int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows, int32_t* fb_count,
-                       hipStream_t st) {
+                       hipStream_t st, const int32_t* count_dev) {
+    // (count_dev: NULL, or the device-side number of rows -- count is then the capacity of the list and sizes the grid)
     if (count <= 0) return 0;
     if (!wmf_directl_supported(f, ld)) return -1;
     const int nfb = f / 16;                                      // 4 or 8 (the bias column is a border)
@@ -579,9 +585,9 @@ int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const
 #else
     constexpr bool x6 = true;                                   // (the f32-MFMA accumulation variants are compiled into -DWMF_LAB builds only)
 #endif
-#define DL_LAUNCH(N, B, X) WMF_LAUNCH("solve_directl_kernel<" #N ", " #B ", " #X ", 16, 0>", (solve_directl_kernel<N, B, X>), grid, dim3(64), \
+#define DL_LAUNCH(N, B, X) WMF_LAUNCH(dl_name("solve_directl_kernel<" #N ", " #B ", " #X ", 16, 0>", count_dev != nullptr), (solve_directl_kernel<N, B, X>), grid, dim3(64), \
                                       DL_LDSB(N, 16), st, rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, \
-                                      (const int64_t*)nullptr, (const int32_t*)nullptr, (float*)nullptr)
+                                      (const int64_t*)nullptr, (const int32_t*)nullptr, (float*)nullptr, count_dev)
 #ifdef WMF_LAB
 #define DL_PICK(N) do { if (f % 16) { if (x6) DL_LAUNCH(N, true, true); else DL_LAUNCH(N, true, false); } \
                         else        { if (x6) DL_LAUNCH(N, false, true); else DL_LAUNCH(N, false, false); } } while (0)
@@ -598,12 +604,12 @@ int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const
         // order, i.e. behind every LDS-DMA of the ring (27.3 ms with reloads of spilled lane constants inside the chunk loop,
         // 21.0 with none there, 19.9 with none at all); hipcc puts s_waitcnt vmcnt(0) in front of every LDS access it can see.
         const dim3 grid2((unsigned)(count < 2 * cap ? count : 2 * cap));
-        if (f % 16) WMF_LAUNCH("solve_directl_kernel<8, true, true, 8, 0>", (solve_directl_kernel<8, true, true, 8>), grid2, dim3(64), DL_LDSB(8, 8), st,
+        if (f % 16) WMF_LAUNCH(dl_name("solve_directl_kernel<8, true, true, 8, 0>", count_dev != nullptr), (solve_directl_kernel<8, true, true, 8>), grid2, dim3(64), DL_LDSB(8, 8), st,
                                rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, (const int64_t*)nullptr,
-                               (const int32_t*)nullptr, (float*)nullptr);
-        else WMF_LAUNCH("solve_directl_kernel<8, false, true, 8, 0>", (solve_directl_kernel<8, false, true, 8>), grid2, dim3(64), DL_LDSB(8, 8), st,
+                               (const int32_t*)nullptr, (float*)nullptr, count_dev);
+        else WMF_LAUNCH(dl_name("solve_directl_kernel<8, false, true, 8, 0>", count_dev != nullptr), (solve_directl_kernel<8, false, true, 8>), grid2, dim3(64), DL_LDSB(8, 8), st,
                         rows, count, V, side, indptr, indices, vals, f, ld, g, fb_rows, fb_count, dbg, (const int64_t*)nullptr,
-                        (const int32_t*)nullptr, (float*)nullptr);
+                        (const int32_t*)nullptr, (float*)nullptr, count_dev);
     } else DL_PICK(8);
 #undef DL_PICK
 #undef DL_LAUNCH
@@ -620,9 +626,9 @@ int wmf_launch_directl_segments(int64_t nseg, const float* V, const float* side,
     const int dbg = wmf_debug_flags;
     if (f % 16) WMF_LAUNCH("solve_directl_kernel<8, true, true, 8, 1>", (solve_directl_kernel<8, true, true, 8, 1>), grid, dim3(64), DL_LDSB(8, 8), st,
                            (const int32_t*)nullptr, nseg, V, side, (const int64_t*)nullptr, indices, vals, f, ld, (float*)nullptr,
-                           (int32_t*)nullptr, (int32_t*)nullptr, dbg, seg_lo, seg_d, partial);
+                           (int32_t*)nullptr, (int32_t*)nullptr, dbg, seg_lo, seg_d, partial, (const int32_t*)nullptr);
     else WMF_LAUNCH("solve_directl_kernel<8, false, true, 8, 1>", (solve_directl_kernel<8, false, true, 8, 1>), grid, dim3(64), DL_LDSB(8, 8), st,
                     (const int32_t*)nullptr, nseg, V, side, (const int64_t*)nullptr, indices, vals, f, ld, (float*)nullptr,
-                    (int32_t*)nullptr, (int32_t*)nullptr, dbg, seg_lo, seg_d, partial);
+                    (int32_t*)nullptr, (int32_t*)nullptr, dbg, seg_lo, seg_d, partial, (const int32_t*)nullptr);
     return 0;
 }

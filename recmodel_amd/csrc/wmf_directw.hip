@@ -88,7 +88,8 @@ __global__ __launch_bounds__(64, DwCfg<NFB>::OCC) void solve_directw_kernel(cons
                                                               int32_t* __restrict__ fb_count, int dbg,
                                                               const int64_t* __restrict__ seg_lo, const int32_t* __restrict__ seg_d,
                                                               const int32_t* __restrict__ seg_first, float* __restrict__ partial,
-                                                              int slot_a, int slot_b) {
+                                                              int slot_a, int slot_b, const int32_t* __restrict__ count_dev) {
+    if (count_dev) count = *count_dev;                           // (the rows the iteration kernel bounced: the count is on the device)
     constexpr int NT = NFB * (NFB + 1) / 2;
     constexpr int GS = DwCfg<NFB>::GS;                           // MFMA k-steps (4 entries each) per pipelined group
     __shared__ __attribute__((aligned(16))) float Wv[NFB * 16];              // w_p = X_p y_p, kept for the backward pass
@@ -291,18 +292,35 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
     const int64_t cap = 256 * waves_per_cu * 3;                  // resident waves, three rounds queued
     const int32_t* rows = pl->rows[WMF_BIN_MFMA];
     const int64_t normal = pl->count[WMF_BIN_MFMA] - pl->heavy_count;
-    // k = 128 with or without biases: the LDS-DMA ring kernel (wmf_directl.hip); debug flag 4096 keeps the register ring
-    // and k = 64 since round 2: with the split-f16 accumulation AND elimination the LDS-DMA kernel, two waves per SIMD there,
-    // takes 0.97 ms for cfg2's item side where the f32 register-ring kernel takes 1.39 (round 1, bf16 x 3 accumulation
-    // and f32 elimination: 1.34 against 1.30; debug flag 65536 keeps the register ring at k = 64)
-    // (side: NULL, or the {last feature, bias} pairs of the split layout, V then being the packed body)
-    if (normal > 0 && wmf_directl_supported(f, ld) && !(dbg & 4096) && (f >= 128 || !(dbg & 65536))) {
-        (void)wmf_launch_directl(rows, normal, V, side, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, st);
-    } else if (normal > 0) {
-        static const char* nm = wmf_kname("solve_directw_kernel<%d, 0, %s>", NFB, BORDER ? "true" : "false");
-        WMF_LAUNCH(nm, (solve_directw_kernel<NFB, 0, BORDER>), dim3((unsigned)(normal < cap ? normal : cap)), dim3(64), 0, st,
-                   rows, normal, V, side, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
-                   nullptr, nullptr, nullptr, nullptr, 1, 0);
+    // ROUND 4: the first iter_count of the normal rows (at most wmf_iter_dmax entries each, wmf_plan_create) go to the
+    // matrix-free iteration kernel (wmf_iter.hip); what it cannot solve to float32 accuracy in a few applications of the
+    // row's operator comes back as a device-side list and is eliminated below like every other row.  Debug flag 268435456
+    // switches the iteration off (everything eliminated, as in round 3).
+    const int64_t n_iter = wmf_iter_rows(pl, f, ld, side != nullptr);
+    if (n_iter > 0)
+        (void)wmf_launch_iter(rows, n_iter, V, side, indptr, indices, vals, f, ld, g, pl->iter_bounce_rows, pl->fallback_count + 1,
+                              pl->iter_stats, st);
+    // two launches of the elimination kernel: the rows that were never candidates (count on the host), then the bounced ones
+    // (count on the device; the grid is sized for the list's capacity and exits at once when the list is empty)
+    for (int pass = 0; pass < 2; ++pass) {
+        const int32_t* prow = pass ? pl->iter_bounce_rows : rows + n_iter;
+        const int64_t pcount = pass ? n_iter : normal - n_iter;
+        const int32_t* pdev = pass ? pl->fallback_count + 1 : nullptr;
+        if (pcount <= 0) continue;
+        // k = 128 with or without biases: the LDS-DMA ring kernel (wmf_directl.hip); debug flag 4096 keeps the register ring
+        // and k = 64 since round 2: with the split-f16 accumulation AND elimination the LDS-DMA kernel, two waves per SIMD there,
+        // takes 0.97 ms for cfg2's item side where the f32 register-ring kernel takes 1.39 (round 1, bf16 x 3 accumulation
+        // and f32 elimination: 1.34 against 1.30; debug flag 65536 keeps the register ring at k = 64)
+        // (side: NULL, or the {last feature, bias} pairs of the split layout, V then being the packed body)
+        if (wmf_directl_supported(f, ld) && !(dbg & 4096) && (f >= 128 || !(dbg & 65536))) {
+            (void)wmf_launch_directl(prow, pcount, V, side, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, st, pdev);
+        } else {
+            static const char* nm = wmf_kname("solve_directw_kernel<%d, 0, %s>", NFB, BORDER ? "true" : "false");
+            static const char* nmb = wmf_kname("solve_directw_kernel<%d, 0, %s> [bounced]", NFB, BORDER ? "true" : "false");
+            WMF_LAUNCH(pass ? nmb : nm, (solve_directw_kernel<NFB, 0, BORDER>), dim3((unsigned)(pcount < cap ? pcount : cap)), dim3(64), 0, st,
+                       prow, pcount, V, side, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
+                       nullptr, nullptr, nullptr, nullptr, 1, 0, pdev);
+        }
     }
     if (pl->heavy_count > 0) {
         const int64_t nseg = pl->seg_total;
@@ -314,12 +332,12 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
         } else
         WMF_LAUNCH(nm1, (solve_directw_kernel<NFB, 1, BORDER>), dim3((unsigned)(nseg < cap ? nseg : cap)), dim3(64), 0, st, rows,
                    nseg, V, side, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg, pl->seg_lo,
-                   pl->seg_d, pl->seg_first, pl->partial, 1, 0);
+                   pl->seg_d, pl->seg_first, pl->partial, 1, 0, (const int32_t*)nullptr);
         const int64_t nh = pl->heavy_count;
         wmf_launch_combine_segments(pl, WMF_DW_PARTIAL(NFB, BORDER), st);
         WMF_LAUNCH(nm2, (solve_directw_kernel<NFB, 2, BORDER>), dim3((unsigned)(nh < cap ? nh : cap)), dim3(64), 0, st,
                    rows + normal, nh, V, side, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count, dbg,
-                   pl->seg_lo, pl->seg_d, pl->seg_first, pl->partial, 0, 0);
+                   pl->seg_lo, pl->seg_d, pl->seg_first, pl->partial, 0, 0, (const int32_t*)nullptr);
     }
 }
 
@@ -333,7 +351,7 @@ static void launch_accumulate_nfb(const float* V, const float* side, const int64
     static const char* nm = wmf_kname("solve_directw_kernel<%d, 1, %s>", NFB, BORDER ? "true" : "false");
     WMF_LAUNCH(nm, (solve_directw_kernel<NFB, 1, BORDER>), dim3((unsigned)(n < cap ? n : cap)), dim3(64), 0, st, nullptr, n, V,
                side, indptr, indices, vals, f, ld, nullptr, nullptr, nullptr, wmf_debug_flags & ~3, indptr, degrees,
-               nullptr, partial, slot_stride, slot_offset);
+               nullptr, partial, slot_stride, slot_offset, (const int32_t*)nullptr);
 }
 template <int NFB, bool BORDER>
 static void launch_eliminate_nfb(float* partial, int64_t n, int slots_per_row, int f, int ld, float* g, int32_t* fb_rows,
@@ -342,7 +360,7 @@ static void launch_eliminate_nfb(float* partial, int64_t n, int slots_per_row, i
     static const char* nm = wmf_kname("solve_directw_kernel<%d, 2, %s>", NFB, BORDER ? "true" : "false");
     WMF_LAUNCH(nm, (solve_directw_kernel<NFB, 2, BORDER>), dim3((unsigned)(n < cap ? n : cap)), dim3(64), 0, st, nullptr, n,
                nullptr, nullptr, nullptr, nullptr, nullptr, f, ld, g, fb_rows, fail_count, wmf_debug_flags & ~3, nullptr,
-               nullptr, nullptr, partial, slots_per_row, 0);
+               nullptr, nullptr, partial, slots_per_row, 0, (const int32_t*)nullptr);
 }
 static bool dw_border(int f) { return wmf_dw_border(f); }
 

@@ -34,6 +34,12 @@ struct wmf_plan {
     int32_t* seg_first;        // device: heavy_count + 1 prefix of segment counts
     float* partial;            // device: seg_total x (tiles x 256) partial accumulators
     float* wide_ws;            // device: workspace of the f > 144 pivoted-LU fallback
+    // round 4: the first iter_count rows of the heavy bin's ordinary rows have at most wmf_iter_dmax entries: candidates of the
+    // matrix-free iteration kernel (wmf_iter.hip); fallback_count[1] counts the rows it hands back in iter_bounce_rows
+    int64_t iter_count, iter_nnz;
+    int iter_dmax;             // the candidates' longest admissible row at the width / layout the plan was created for
+    int32_t* iter_bounce_rows; // device: iter_count slots
+    unsigned long long* iter_stats;   // device: 4 counters, accumulated over the launches (wmf_plan_iter_stats reads and clears)
 };
 
 int wmf_gram_max_waves(int f);
@@ -63,9 +69,10 @@ static inline bool wmf_split_layout(int f, int ld) { return wmf_dw_border(f) && 
 // wmf_directl.hip: normal heavy rows at f = 128 / 129 through an LDS-DMA row ring
 int wmf_directl_supported(int f, int ld);
 // (side: NULL, or the {last feature, bias} pairs of the split layout; V is then the packed body)
+// (count_dev: NULL, or the device-side number of rows; count is then the capacity of the list -- the bounce list of wmf_iter.hip)
 int wmf_launch_directl(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
                        const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows, int32_t* fb_count,
-                       hipStream_t st);
+                       hipStream_t st, const int32_t* count_dev = nullptr);
 int wmf_launch_directl_segments(int64_t nseg, const float* V, const float* side, const int32_t* indices, const float* vals, int f,
                                 int ld, const int64_t* seg_lo, const int32_t* seg_d, float* partial, hipStream_t st);
 int wmf_launch_directw(const wmf_plan* pl, const float* V, const float* side, const int64_t* indptr,
@@ -86,7 +93,19 @@ int wmf_launch_coo_to_csr(const int64_t* rows, const int64_t* cols, const float*
 int wmf_wide_supported(int f);
 int wmf_launch_wide(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                     const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
-                    int32_t* fb_count, hipStream_t st);
+                    int32_t* fb_count, hipStream_t st, const int32_t* count_dev = nullptr);
+// wmf_iter.hip: rows with 33 .. wmf_iter_dmax entries whose whitened system is close to the identity, by a matrix-free
+// Neumann / Chebyshev iteration; the rows it does not solve are appended to bounce_rows (count on the device)
+int wmf_iter_dmax(int f, int ld, int split);
+int wmf_launch_iter(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
+                    const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* bounce_rows,
+                    int32_t* bounce_count, unsigned long long* stats, hipStream_t st);
+static inline bool wmf_iter_enabled() { return !(wmf_debug_flags & 268435456); }
+// candidates of this call: none when the iteration is switched off, or when the call's layout (ld, split) is not the one the
+// plan sorted its rows for (a caller with its own leading dimension: the kernel's register slots would not hold the rows)
+static inline int64_t wmf_iter_rows(const wmf_plan* pl, int f, int ld, bool split) {
+    return (wmf_iter_enabled() && pl->iter_count > 0 && wmf_iter_dmax(f, ld, split ? 1 : 0) >= pl->iter_dmax) ? pl->iter_count : 0;
+}
 int wmf_rowsplit_supported(int f);
 int wmf_launch_rowsplit(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
                         const int32_t* indices, const float* vals, int f, int ld, float* g, hipStream_t st);

@@ -1,0 +1,518 @@
+// Rows with more than 32 stored entries whose whitened system is close to the identity: a MATRIX-FREE polynomial iteration
+// instead of forming and eliminating the f x f system (gfx950; round 4).
+//
+//   (I + E) g = b,   E = V_u^T D V_u,   b = V_u^T p          (RecModel/wmf_model.py:233-239 in whitened coordinates)
+//
+// The whitening bounds the whole fixed side by  sum_i v_i v_i^T <= I  (V = Y L^-T with L L^T = Y^T Y + lambda I), so a row that
+// touches d of its m rows has  ||E||_2 <= tr E = sum_e w_e |v_e|^2 =: tau,  about  w d f / m  -- 0.013 for the item rows of
+// BASELINE.json's configs[2] (d ~ 100 of m = 10^7 users), 0.13 / 0.26 for configs[1] / the one-GPU slice of configs[4].  Then
+//     g = b - E b + E^2 b - ...                                         (tau <= tau_neumann; error after k terms <= tau^k)
+// or the Chebyshev iteration on the spectrum bound [1 - tau_minus, 1 + tau_plus] (larger tau; tau_minus = the same sum over
+// the negative weights a bias model can have) needs a handful of applications of E, and E d = V_u^T (D (V_u d)) is two passes
+// over the GATHERED ROWS -- 2 d f multiply-adds -- where forming E costs d f^2 / 2 and eliminating it f^3 / 3: at f = 129,
+// d = 100 four applications are 1 / 15 of the direct method's arithmetic, all of it plain f32 FMAs (no split-f16 operands: the
+// result is accurate to f32 rounding of E d, better than the MFMA path).  The stopping test is on the true residual,
+//     |r_k| phi <= eps |b| (1 - tau_minus),      phi = tau (Neumann) or delta / theta (Chebyshev),
+// after which one more Richardson step x += r / theta costs nothing (its error is <= phi |A^-1 r|).  A row whose bound is too
+// weak (kappa = (1 + tau_plus) / (1 - tau_minus) > kappa_max, tau_minus > 1/2) or that has not converged after kmax
+// applications is BOUNCED: its id goes to a device-side list that the elimination kernels (wmf_directl / wmf_directw /
+// wmf_rowsplit / wmf_wide) then solve as before.  Which path a row takes depends on its own data only, so results are
+// reproducible bit for bit; the fraction of rows on each path is data dependent and is reported (wmf_plan_iter_stats).
+//
+// Work split.  One WORKGROUP of NW waves per row; the gathered rows live in REGISTERS from the first pass to the last:
+// entry e = 4 NW s + 4 w + q of the row sits in slot s of wave w, lane group q = lane >> 4, whose 16 lanes r = lane & 15
+// hold FPL consecutive features each (r FPL .. r FPL + FPL - 1; f <= 16 FPL, or 16 FPL + 1 with the border feature of the
+// split layout, wmf_internal.h) -- a 16-lane group reads one whole row, 16-byte pieces, coalesced.  A vector of the
+// iteration (x, r, d) is held in "feature layout": lane (q, r) has elements r FPL .., replicated over q and over the waves.
+//   pass A   t_e = w_e (v_e . d): FPL / 2 packed FMAs per slot, then a sum over the 16 lanes of a group (four DPP adds that
+//            serve the four entries of a slot at once);
+//   pass B   z = sum_e t_e v_e: FPL / 2 packed FMAs per slot; the sum over the four lane groups is a reduce-scatter by lane
+//            swaps (v_permlane32_swap / v_permlane16_swap: six instructions per four values), the sum over the waves goes
+//            through LDS in a fixed order: one workgroup barrier per application of E.
+// 4 waves x 3 workgroups per CU at f <= 144 (168 registers), 8 waves x 1 workgroup at f > 144; the next row's column ids are
+// fetched a row ahead, so a row switch costs one memory latency, hidden by the other workgroups of the CU.
+#include "wmf_common.h"
+#include "wmf_internal.h"
+
+typedef float it_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int it_bits(float v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ float it_flt(int v) { return __builtin_bit_cast(float, v); }
+
+// lane (q, r) gets the sum over the four 16-lane groups of a_q -- a reduce-scatter: three swaps, three adds, fixed order
+__device__ __forceinline__ float it_rs4(float a0, float a1, float a2, float a3) {
+    const auto s02 = __builtin_amdgcn_permlane32_swap(it_bits(a0), it_bits(a2), false, false);   // {a0.lo a2.lo}, {a0.hi a2.hi}
+    const float t02 = it_flt((int)s02[0]) + it_flt((int)s02[1]);
+    const auto s13 = __builtin_amdgcn_permlane32_swap(it_bits(a1), it_bits(a3), false, false);
+    const float t13 = it_flt((int)s13[0]) + it_flt((int)s13[1]);
+    const auto u = __builtin_amdgcn_permlane16_swap(it_bits(t02), it_bits(t13), false, false);   // odd groups of t02 <-> even groups of t13
+    return it_flt((int)u[0]) + it_flt((int)u[1]);
+}
+
+template <int NW, int FPL>
+struct ItLds {
+    static constexpr int FEAT = 16 * FPL;
+    static constexpr int VEC = NW * FEAT;              // floats of one buffer of partial vectors
+    static constexpr int EXCH = 2 * (VEC + NW * 4);    // two buffers (an exchange writes the one the previous did not)
+};
+
+// counters of a launch (per plan, wmf_plan_iter_stats): rows solved here, rows bounced, applications of E in total
+enum { IT_STAT_DONE = 0, IT_STAT_BOUNCED = 1, IT_STAT_APPLICATIONS = 2, IT_STAT_CHEB = 3 };
+
+// FULL: every lane's pieces lie inside a row (16 FPL floats per gathered row exactly: k = 64, 128, 256 with or without the
+// split layout's border) -- no piece masks in the gather.
+template <int NW, int FPL, int NS, bool SPLIT, bool FULL, int OCC>
+__global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t* __restrict__ rows, int64_t count,
+                                                                 const float* __restrict__ V, const float* __restrict__ side,
+                                                                 const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                                 const float* __restrict__ vals, int f, int ld, float* __restrict__ g,
+                                                                 int32_t* __restrict__ bounce_rows, int32_t* __restrict__ bounce_count,
+                                                                 float tau_neumann, float kappa_max, int kmax, float eps2,
+                                                                 unsigned long long* __restrict__ stats) {
+    constexpr int H = FPL / 2, P4 = FPL / 4, EPS = 4 * NW;
+    using L = ItLds<NW, FPL>;
+    __shared__ __attribute__((aligned(16))) float lds[L::EXCH];
+    __shared__ int next_ids[NS][64 * NW];               // the next row's column ids wait here, not in registers
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int ldv = FULL ? 16 * FPL : (SPLIT ? f - 1 : ld);   // floats between gathered rows (split layout: the packed body)
+    const float m0 = (r == 0) ? 1.f : 0.f;              // the border feature is counted by one lane of a group
+    // 16-byte pieces of this lane that lie inside a row (f not a multiple of 64: the last lanes have fewer, or none)
+    bool pin[P4];
+#pragma unroll
+    for (int j = 0; j < P4; ++j) pin[j] = FULL || r * FPL + 4 * j < ldv;
+
+    unsigned long long st_done = 0, st_bounced = 0, st_apps = 0, st_cheb = 0;
+    int parity = 0;                                     // exchange buffer to write next
+
+    // ---- the next row's column ids, a row ahead ----------------------------------------------------------------
+    int64_t it = blockIdx.x;
+    int u = 0, d = 0;
+    int64_t lo = 0;
+    int idx[NS];
+    auto row_of = [&](int64_t i, int& uu, int64_t& l, int& dd) {
+        uu = rows[i];
+        l = indptr[uu];
+        dd = (int)(indptr[uu + 1] - l);
+    };
+    auto fetch_ids = [&](int64_t l, int dd, int (&id)[NS]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int e = EPS * s + 4 * wv + q;
+            id[s] = indices[l + (e < dd ? e : 0)];      // (unconditional: a select against a constant would make the register
+                                                        // write wait for every request in flight; entry 0 again is an L1 hit)
+        }
+    };
+    // (the first row's ids go through LDS like every later row's: one code path, and no request of the row loop ever waits on
+    // a load that was issued outside it)
+    if (it < count) {
+        row_of(it, u, lo, d);
+        fetch_ids(lo, d, idx);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) next_ids[s][threadIdx.x] = idx[s];
+    }
+
+    for (; it < count; it += gridDim.x) {
+        const int ns = (d + EPS - 1) / EPS;             // slots in use (wave uniform)
+        const int ns4 = (ns + 3) & ~3;                  // ... rounded up to the groups of four the passes work in
+#pragma unroll
+        for (int s = 0; s < NS; ++s) idx[s] = next_ids[s][threadIdx.x];
+        // ---- gather: REQUESTS ONLY (nothing in this loop reads what it loads, so no wait separates the slots' requests):
+        // body pieces, weight, border / bias pair of every entry of this wave
+        it_f32x2 vb[NS][H], pr[NS];
+        float vbd[NS], wt[NS];
+        // (first the zero entries that fill the last group of four -- a register write behind the requests would wait for them)
+#pragma unroll
+        for (int s = 1; s < NS; ++s) {
+            if (s >= ns && s < ns4) {
+#pragma unroll
+                for (int j = 0; j < H; ++j) vb[s][j] = it_f32x2{0.f, 0.f};
+                wt[s] = 0.f;
+                pr[s] = it_f32x2{0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s < ns) {
+                const int e = EPS * s + 4 * wv + q;
+                const float* row = V + (int64_t)idx[s] * ldv + r * FPL;
+#pragma unroll
+                for (int j = 0; j < P4; ++j) {
+                    const f32x4 piece = *reinterpret_cast<const f32x4*>((FULL || pin[j]) ? row + 4 * j : V);
+                    vb[s][2 * j] = it_f32x2{piece[0], piece[1]};
+                    vb[s][2 * j + 1] = it_f32x2{piece[2], piece[3]};
+                }
+                wt[s] = vals[lo + (e < d ? e : 0)];
+                if constexpr (SPLIT) pr[s] = *reinterpret_cast<const it_f32x2*>(side + 2 * (int64_t)idx[s]);
+            }
+        }
+        // the row after this one: ids requested now, parked in LDS behind pass 0, used at the next trip
+        const int64_t itn = it + gridDim.x;
+        int un = 0, dn = 0;
+        int64_t lon = 0;
+        int idn[NS];
+        if (itn < count) { row_of(itn, un, lon, dn); fetch_ids(lon, dn, idn); }
+
+        // ---- one exchange: z (feature partials of this wave's entries) and NSC scalars -> totals over the row --------------
+        auto exchange = [&]<int NSC>(std::integral_constant<int, NSC>, it_f32x2 (&z)[H], float& zb, float& s1, float& s2) {
+            float* vec = lds + parity * (L::VEC + NW * 4);
+            float* sc = vec + L::VEC;
+#pragma unroll
+            for (int j = 0; j < P4; ++j) {
+                const float tot = it_rs4(z[2 * j][0], z[2 * j][1], z[2 * j + 1][0], z[2 * j + 1][1]);   // feature r FPL + 4 j + q
+                vec[wv * L::FEAT + r * FPL + 4 * j + q] = tot;
+            }
+            if constexpr (NSC > 0) {
+                const float tsc = NSC > 1 ? it_rs4(zb, s1, s2, 0.f) : wmf_qsum(zb);
+                if (r == 0 && (NSC > 1 || q == 0)) sc[wv * 4 + q] = tsc;
+            }
+            __syncthreads();
+            // (where registers allow -- four waves at two workgroups per CU -- every partial vector is requested before the first is
+            // added; the sums are in wave order either way)
+            constexpr bool BATCH = NW == 4 && OCC == 2;
+            f32x4 acc[P4], part[BATCH ? 3 : 1][P4];
+#pragma unroll
+            for (int j = 0; j < P4; ++j) acc[j] = *reinterpret_cast<const f32x4*>(vec + r * FPL + 4 * j);
+            if constexpr (BATCH) {
+#pragma unroll
+                for (int w2 = 1; w2 < 4; ++w2)
+#pragma unroll
+                    for (int j = 0; j < P4; ++j) part[w2 - 1][j] = *reinterpret_cast<const f32x4*>(vec + w2 * L::FEAT + r * FPL + 4 * j);
+            }
+            if constexpr (NSC > 1) {
+                f32x4 sacc = *reinterpret_cast<const f32x4*>(sc);
+#pragma unroll
+                for (int w2 = 1; w2 < NW; ++w2) sacc += *reinterpret_cast<const f32x4*>(sc + 4 * w2);
+                zb = sacc[0]; s1 = sacc[1]; s2 = sacc[2];
+            } else if constexpr (NSC == 1) {
+                float a = sc[0];
+#pragma unroll
+                for (int w2 = 1; w2 < NW; ++w2) a += sc[4 * w2];
+                zb = a;
+            }
+            if constexpr (BATCH) {
+#pragma unroll
+                for (int w2 = 1; w2 < 4; ++w2)                   // (a fixed order: wave 0, 1, ..)
+#pragma unroll
+                    for (int j = 0; j < P4; ++j) acc[j] += part[w2 - 1][j];
+            } else {
+#pragma unroll
+                for (int w2 = 1; w2 < NW; ++w2)
+#pragma unroll
+                    for (int j = 0; j < P4; ++j) acc[j] += *reinterpret_cast<const f32x4*>(vec + w2 * L::FEAT + r * FPL + 4 * j);
+            }
+#pragma unroll
+            for (int j = 0; j < P4; ++j) { z[2 * j] = it_f32x2{acc[j][0], acc[j][1]}; z[2 * j + 1] = it_f32x2{acc[j][2], acc[j][3]}; }
+            parity ^= 1;
+        };
+        // sum of squares of a vector in feature layout (the same bits on every lane of every wave), as a wave-uniform value
+        auto norm2 = [&](const it_f32x2 (&v)[H], float vbr) {
+            it_f32x2 a = v[0] * v[0];
+            if constexpr (H > 1) {
+                it_f32x2 a2 = v[1] * v[1];
+#pragma unroll
+                for (int j = 2; j < H; j += 2) { a = v[j] * v[j] + a; a2 = v[j + 1] * v[j + 1] + a2; }
+                a += a2;
+            }
+            float t = a[0] + a[1];
+            if constexpr (SPLIT) t = __builtin_fmaf(m0 * vbr, vbr, t);
+            return it_flt(__builtin_amdgcn_readfirstlane(it_bits(wmf_row16_sum(t))));
+        };
+        // z = E y = V_u^T (D (V_u y)) over this wave's entries (partials: the caller's exchange sums them): pass A, t_e = w_e (v_e . y),
+        // and pass B, z += t_e v_e, four slots at a time -- four independent chains, one 16-lane sum for the four
+        auto apply = [&](const it_f32x2 (&y)[H], float yb, it_f32x2 (&z)[H], float& zb) {
+            zb = 0.f;
+#pragma unroll
+            for (int j = 0; j < H; ++j) z[j] = it_f32x2{0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < NS; s4 += 4) {
+                if (s4 < ns) {
+                    it_f32x2 a[4];
+                    float tt[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i] = (s4 + i < NS) ? vb[s4 + i < NS ? s4 + i : 0][0] * y[0] : it_f32x2{0.f, 0.f};
+#pragma unroll
+                    for (int j = 1; j < H; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (s4 + i < NS) a[i] = vb[s4 + i < NS ? s4 + i : 0][j] * y[j] + a[i];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        tt[i] = a[i][0] + a[i][1];
+                        if constexpr (SPLIT) { if (s4 + i < NS) tt[i] = __builtin_fmaf(vbd[s4 + i < NS ? s4 + i : 0], yb, tt[i]); }
+                    }
+                    wmf_row16_sum4(tt[0], tt[1], tt[2], tt[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (s4 + i < NS) {
+                            const int s = s4 + i;
+                            const float t = tt[i] * wt[s];
+#pragma unroll
+                            for (int j = 0; j < H; ++j) z[j] = vb[s][j] * it_f32x2{t, t} + z[j];
+                            if constexpr (SPLIT) zb = __builtin_fmaf(t, vbd[s], zb);
+                        }
+                    }
+                }
+            }
+        };
+
+        // ---- pass 0 (the first reader of what the gather requested: slot by slot as the rows land): the entry's weight and
+        // border value, b = V_u^T p, tau_plus / tau_minus = sum of |w| |v|^2 over the positive / negative weights
+        it_f32x2 bv[H];
+        float bb = 0.f, tp = 0.f, tn = 0.f;
+#pragma unroll
+        for (int j = 0; j < H; ++j) bv[j] = it_f32x2{0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s < ns) {
+                const bool valid = EPS * s + 4 * wv + q < d;
+                float w = wt[s];
+                if constexpr (SPLIT) {
+                    vbd[s] = pr[s][0] * m0;
+                    w -= pr[s][1];                       // the fixed side's bias comes with the row (RecModel/wmf_model.py:343)
+                }
+                w = valid ? w : 0.f;
+                wt[s] = w;
+                const float pp = valid ? w + 1.f : 0.f;  // p = w + 1 (wmf_model.py:239); nothing for the lanes past the row's end
+                if constexpr (!FULL) {
+#pragma unroll
+                    for (int j = 0; j < P4; ++j)
+                        if (!pin[j]) { vb[s][2 * j] = it_f32x2{0.f, 0.f}; vb[s][2 * j + 1] = it_f32x2{0.f, 0.f}; }
+                }
+                it_f32x2 n2 = vb[s][0] * vb[s][0], n2b = vb[s][1] * vb[s][1];
+#pragma unroll
+                for (int j = 0; j < H; ++j) {
+                    bv[j] = vb[s][j] * it_f32x2{pp, pp} + bv[j];
+                    if (j >= 2) { if (j & 1) n2b = vb[s][j] * vb[s][j] + n2b; else n2 = vb[s][j] * vb[s][j] + n2; }
+                }
+                n2 += n2b;
+                float nn = n2[0] + n2[1];
+                if constexpr (SPLIT) {
+                    bb = __builtin_fmaf(pp, vbd[s], bb);
+                    nn = __builtin_fmaf(vbd[s], vbd[s], nn);
+                }
+                tp = __builtin_fmaf(fmaxf(w, 0.f), nn, tp);
+                tn = __builtin_fmaf(fmaxf(-w, 0.f), nn, tn);
+            } else if (s < ns4) {
+                vbd[s] = 0.f;
+            }
+        }
+        tp = wmf_row16_sum(tp);
+        tn = wmf_row16_sum(tn);
+        if (itn < count) {                                  // (the ids have landed behind the rows of pass 0)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) next_ids[s][threadIdx.x] = idn[s];
+        }
+        exchange(std::integral_constant<int, 3>{}, bv, bb, tp, tn);
+        tp = it_flt(__builtin_amdgcn_readfirstlane(it_bits(tp)));
+        tn = it_flt(__builtin_amdgcn_readfirstlane(it_bits(tn)));
+        const float nb = norm2(bv, bb);
+
+        // ---- the iteration's constants (wave uniform; the same on every wave of the workgroup) ----------------------------
+        const float tau = tp + tn;
+        const float alo = 1.f - tn, chi = 1.f + tp;             // the spectrum of I + E lies in [alo, chi]
+        // (v_rcp_f32 / v_sqrt_f32 are accurate to one ulp: these constants steer the recurrence, they are not part of the answer)
+        const float theta = 0.5f * (chi + alo), delta = 0.5f * (chi - alo), itheta = __builtin_amdgcn_rcpf(theta);
+        const bool cheb_ok = tn <= 0.5f && chi <= kappa_max * alo;
+        const float sk = __builtin_amdgcn_sqrtf(chi * __builtin_amdgcn_rcpf(fmaxf(alo, 0.25f)));
+        const float sigma = (sk - 1.f) * __builtin_amdgcn_rcpf(sk + 1.f);   // the Chebyshev iteration's asymptotic rate on that interval
+        const float stop = eps2 * nb * alo * alo;
+        bool converged = false, cheb = !(tau <= tau_neumann);
+        const bool go = cheb ? cheb_ok : true;
+        int napp = 0;
+
+        it_f32x2 xv[H], rv[H];
+        float xb = bb, rb = bb;
+#pragma unroll
+        for (int j = 0; j < H; ++j) { xv[j] = bv[j]; rv[j] = bv[j]; }
+        if (go && !cheb) {
+            // Neumann: x = sum_k (-E)^k b.  rv holds y = E^k b; the residual of the x BEFORE a term is added is that term.
+            float sign = -1.f, nprev = nb;
+            for (; napp < kmax;) {
+                it_f32x2 z[H];
+                float zb, z1 = 0.f, z2 = 0.f;
+                apply(rv, rb, z, zb);
+                exchange(std::integral_constant<int, SPLIT ? 1 : 0>{}, z, zb, z1, z2);
+                ++napp;
+                const float nr = norm2(z, zb);
+                if (nr * tau * tau <= stop) {                   // adding this term leaves an error <= tau |A^-1 z|
+#pragma unroll
+                    for (int j = 0; j < H; ++j) xv[j] = z[j] * it_f32x2{sign, sign} + xv[j];
+                    if constexpr (SPLIT) xb = __builtin_fmaf(sign, zb, xb);
+                    converged = true;
+                    break;
+                }
+                // contracting slowly (the row's operator has an eigenvalue near its bound tau): the Chebyshev recurrence on
+                // [alo, chi] does better from here, started from the present x with this term as its residual
+                if (cheb_ok && nr > fmaxf(sigma * sigma, 0.01f) * nprev) {
+#pragma unroll
+                    for (int j = 0; j < H; ++j) rv[j] = z[j] * it_f32x2{sign, sign};
+                    if constexpr (SPLIT) rb = sign * zb;
+                    cheb = true;
+                    break;
+                }
+#pragma unroll
+                for (int j = 0; j < H; ++j) { xv[j] = z[j] * it_f32x2{sign, sign} + xv[j]; rv[j] = z[j]; }
+                if constexpr (SPLIT) { xb = __builtin_fmaf(sign, zb, xb); rb = zb; }
+                sign = -sign;
+                nprev = nr;
+            }
+        } else if (go) {
+#pragma unroll
+            for (int j = 0; j < H; ++j) xv[j] = it_f32x2{0.f, 0.f};   // Chebyshev from x = 0, r = b
+            xb = 0.f;
+        }
+        if (go && cheb && !converged && cheb_ok) {
+            // Chebyshev iteration for (I + E) x = b on [alo, chi] from (x, r): d_0 = r / theta, then
+            //   x += d;  r -= (I + E) d;  rho' = 1 / (2 sigma_1 - rho);  d = rho' rho d + (2 rho' / delta) r        (sigma_1 = theta / delta)
+            it_f32x2 dv[H];
+            float db = rb * itheta, rho0 = delta * itheta;
+            const float phi = delta * itheta;
+#pragma unroll
+            for (int j = 0; j < H; ++j) dv[j] = rv[j] * it_f32x2{itheta, itheta};
+            for (; napp < kmax;) {
+#pragma unroll
+                for (int j = 0; j < H; ++j) xv[j] += dv[j];
+                if constexpr (SPLIT) xb += db;
+                it_f32x2 z[H];
+                float zb, z1 = 0.f, z2 = 0.f;
+                apply(dv, db, z, zb);
+                exchange(std::integral_constant<int, SPLIT ? 1 : 0>{}, z, zb, z1, z2);
+                ++napp;
+#pragma unroll
+                for (int j = 0; j < H; ++j) rv[j] = rv[j] - dv[j] - z[j];
+                if constexpr (SPLIT) rb = rb - db - zb;
+                const float nr = norm2(rv, rb);
+                if (nr * phi * phi <= stop) {           // one Richardson step more is free: its error is <= phi |A^-1 r|
+#pragma unroll
+                    for (int j = 0; j < H; ++j) xv[j] = rv[j] * it_f32x2{itheta, itheta} + xv[j];
+                    if constexpr (SPLIT) xb = __builtin_fmaf(rb, itheta, xb);
+                    converged = true;
+                    break;
+                }
+                const float irho = __builtin_amdgcn_rcpf(2.f * theta - rho0 * delta);   // rho_1 / delta, rho_1 = 1 / (2 sigma_1 - rho_0)
+                const float rho1 = delta * irho;
+                const float alpha = 2.f * irho, beta = rho1 * rho0;
+                rho0 = rho1;
+#pragma unroll
+                for (int j = 0; j < H; ++j) dv[j] = rv[j] * it_f32x2{alpha, alpha} + dv[j] * it_f32x2{beta, beta};
+                if constexpr (SPLIT) db = alpha * rb + beta * db;
+            }
+        }
+        if (converged) {
+            if (wv == 0 && q == 0) {
+                float* out = g + (int64_t)u * ld;
+#pragma unroll
+                for (int j = 0; j < P4; ++j) {
+                    const int c = r * FPL + 4 * j;
+                    if (FULL || c < ldv) *reinterpret_cast<f32x4*>(out + c) = f32x4{xv[2 * j][0], xv[2 * j][1], xv[2 * j + 1][0], xv[2 * j + 1][1]};
+                }
+                if (SPLIT && r == 0) *reinterpret_cast<f32x4*>(out + f - 1) = f32x4{xb, 0.f, 0.f, 0.f};
+            }
+            st_done++;
+            st_apps += napp;
+            st_cheb += cheb ? 1 : 0;
+        } else {
+            if (threadIdx.x == 0) bounce_rows[atomicAdd(bounce_count, 1)] = u;
+            st_bounced++;
+        }
+        u = un; lo = lon; d = dn;
+    }
+    if (stats && threadIdx.x == 0) {
+        atomicAdd(stats + IT_STAT_DONE, st_done);
+        atomicAdd(stats + IT_STAT_BOUNCED, st_bounced);
+        atomicAdd(stats + IT_STAT_APPLICATIONS, st_apps);
+        atomicAdd(stats + IT_STAT_CHEB, st_cheb);
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+// Geometry per width: waves per row NW, features per lane FPL (16 FPL floats of a gathered row), slots NS (a workgroup holds
+// 4 NW NS entries), waves per SIMD OCC.  The split layout's extra registers (border value, pair) cost a slot or a workgroup.
+//   ldv <=  64: 4 waves, FPL  4, 16 slots (256 entries), 3 workgroups per CU;  split: 12 slots (192 entries)
+//   ldv <= 128: 4 waves, FPL  8,  9 slots (144 entries), 3 workgroups per CU;  split:  8 slots (128 entries)   (k = 128 +- biases)
+//   ldv <= 192: 8 waves, FPL 12,  8 slots (256 entries), 1 workgroup per CU
+//   ldv <= 256: 8 waves, FPL 16,  8 slots (256 entries), 1 workgroup per CU                                     (k = 256)
+//   ldv <= 320: 8 waves, FPL 20,  6 slots (192 entries), 1 workgroup per CU                                     (f up to 272)
+#ifndef IT_NS64
+#define IT_NS64 16
+#endif
+#ifndef IT_NS64S
+#define IT_NS64S 16
+#endif
+#ifndef IT_NS128
+#define IT_NS128 9
+#endif
+#ifndef IT_NS128S
+#define IT_NS128S 9
+#endif
+#ifndef IT_OCC4
+#define IT_OCC4 3            // waves per SIMD of the four-wave geometries: ldv <= 128 without the split layout ...
+#endif
+#ifndef IT_OCC64
+#define IT_OCC64 2           // ... ldv <= 64 (16 slots) ...
+#endif
+#ifndef IT_OCC4S
+#define IT_OCC4S 2            // (three workgroups per CU spill the pairs: a scratch store of a loaded value waits for the load)
+#endif
+static int it_ldv(int f, int ld, bool split) { return split ? f - 1 : ld; }
+
+// rows of up to this many entries are candidates (0: no kernel for this width)
+int wmf_iter_dmax(int f, int ld, int split) {
+    const int ldv = it_ldv(f, ld, split != 0);
+    if (split && ldv > 128) return 0;
+    if (ldv <= 64) return 16 * (split ? IT_NS64S : IT_NS64);
+    if (ldv <= 128) return 16 * (split ? IT_NS128S : IT_NS128);
+    if (ldv <= 256) return 32 * 8;
+    if (ldv <= 320) return 32 * 6;
+    return 0;
+}
+
+static float it_env(const char* name, float dflt) {
+    const char* s = getenv(name);
+    return s && *s ? (float)atof(s) : dflt;
+}
+
+template <int NW, int FPL, int NS, bool SPLIT, bool FULL, int OCC>
+static void it_launch(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
+                      const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* bounce_rows,
+                      int32_t* bounce_count, unsigned long long* stats, hipStream_t st) {
+    static const char* nm = wmf_kname("solve_iter_kernel<%d, %d, %d, %s, %s, %d>", NW, FPL, NS, SPLIT ? "true" : "false",
+                                      FULL ? "true" : "false", OCC);
+    // policy (environment overrides for experiments): start with the Neumann series while tau <= WMF_ITER_TAU (it converges
+    // for tau < 1, at the rate of the row's LARGEST EIGENVALUE, usually far below tau) and move to the Chebyshev recurrence
+    // when it contracts slower than that would; Chebyshev only while the bound on the condition number is <= WMF_ITER_KAPPA;
+    // at most WMF_ITER_KMAX applications of E
+    static const float tau_n = it_env("WMF_ITER_TAU", 0.8f), kap = it_env("WMF_ITER_KAPPA", 4.f);
+    static const int kmax = (int)it_env("WMF_ITER_KMAX", 20.f);
+    static const float eps = it_env("WMF_ITER_EPS", 6e-8f);      // relative accuracy of a solved row (float32 rounding)
+    const int64_t resident = 256LL * (OCC * 4 / NW);              // workgroups the chip holds
+    const int64_t cap = resident * 4;                            // four rounds queued: rows differ in length
+    WMF_LAUNCH(nm, (solve_iter_kernel<NW, FPL, NS, SPLIT, FULL, OCC>), dim3((unsigned)(count < cap ? count : cap)), dim3(64 * NW), 0, st,
+               rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, tau_n, kap, kmax, eps * eps, stats);
+}
+
+// rows[0 .. count): candidates (more than 32 and at most wmf_iter_dmax entries).  side: NULL, or the {last feature, bias}
+// pairs of the split layout (V is then the packed body).  Rows that are not solved here are appended to bounce_rows.
+int wmf_launch_iter(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
+                    const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* bounce_rows,
+                    int32_t* bounce_count, unsigned long long* stats, hipStream_t st) {
+    if (count <= 0) return 0;
+    const bool split = side != nullptr;
+    const int ldv = it_ldv(f, ld, split);
+#define IT_GO(NW, FPL, NS, SP, OCC)                                                                                                      \
+    do {                                                                                                                                 \
+        if (ldv == 16 * FPL) it_launch<NW, FPL, NS, SP, true, OCC>(rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, stats, st); \
+        else it_launch<NW, FPL, NS, SP, false, OCC>(rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, stats, st);            \
+    } while (0)
+    if (split && ldv > 128) return -1;                            // (the split layout exists for f <= 144 only)
+    if (ldv <= 64) { if (split) IT_GO(4, 4, IT_NS64S, true, IT_OCC4S); else IT_GO(4, 4, IT_NS64, false, IT_OCC64); }
+    else if (ldv <= 128) { if (split) IT_GO(4, 8, IT_NS128S, true, IT_OCC4S); else IT_GO(4, 8, IT_NS128, false, IT_OCC4); }
+    else if (ldv <= 192) IT_GO(8, 12, 8, false, 2);
+    else if (ldv <= 256) IT_GO(8, 16, 8, false, 2);
+    else if (ldv <= 320) IT_GO(8, 20, 6, false, 2);
+    else return -1;
+#undef IT_GO
+    return 0;
+}

@@ -623,7 +623,9 @@ __global__ __launch_bounds__(256, F16A ? RS_OCC16 : 2) void solve_rowsplit_kerne
                                                                 float* __restrict__ g, int32_t* __restrict__ fb_rows,
                                                                 int32_t* __restrict__ fb_count, int dbg,
                                                                 const int64_t* __restrict__ seg_lo, const int32_t* __restrict__ seg_d,
-                                                                const int32_t* __restrict__ seg_first, float* __restrict__ partial) {
+                                                                const int32_t* __restrict__ seg_first, float* __restrict__ partial,
+                                                                const int32_t* __restrict__ count_dev) {
+    if (count_dev) count = *count_dev;                           // (the rows the iteration kernel bounced: the count is on the device)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -637,7 +639,8 @@ __global__ __launch_bounds__(256, F16A ? RS_OCC16 : 2) void solve_rowsplit_kerne
 
 template <int NFB, bool BORDER, bool F16A, int MODE>
 static void launch_rowsplit_f(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
-                              const int32_t* indices, const float* vals, int f, int ld, float* g, const wmf_plan* pl, hipStream_t st) {
+                              const int32_t* indices, const float* vals, int f, int ld, float* g, const wmf_plan* pl, hipStream_t st,
+                              const int32_t* count_dev = nullptr) {
     using C = RsCfg<NFB, BORDER, F16A>;
     constexpr size_t lds = (size_t)C::TOTAL * 4;
     // ROUND-3 FINDING, root cause NOT identified (tests/scale/fuzz_parity.py found it, the lab instrumentation is
@@ -674,9 +677,11 @@ static void launch_rowsplit_f(const int32_t* rows, int64_t count, const float* V
     if (grid > count) grid = count;
     static const char* nm = wmf_kname("solve_rowsplit_kernel<%d, %s, %s, %d>", NFB, BORDER ? "true" : "false",
                                       F16A ? "true" : "false", MODE);
-    WMF_LAUNCH(nm, (solve_rowsplit_kernel<NFB, BORDER, F16A, MODE>), dim3((unsigned)grid), dim3(C::NTHR), lds_launch, st, rows, count, V,
+    static const char* nmb = wmf_kname("solve_rowsplit_kernel<%d, %s, %s, %d> [bounced]", NFB, BORDER ? "true" : "false",
+                                       F16A ? "true" : "false", MODE);
+    WMF_LAUNCH(count_dev ? nmb : nm, (solve_rowsplit_kernel<NFB, BORDER, F16A, MODE>), dim3((unsigned)grid), dim3(C::NTHR), lds_launch, st, rows, count, V,
                biasv, indptr, indices, vals, f, ld, g, pl->fallback_rows, pl->fallback_count,
-               wmf_debug_flags, pl->seg_lo, pl->seg_d, pl->seg_first, pl->partial);
+               wmf_debug_flags, pl->seg_lo, pl->seg_d, pl->seg_first, pl->partial, count_dev);
 }
 
 template <int NFB, bool BORDER>
@@ -689,7 +694,14 @@ static void launch_rowsplit_nfb(const wmf_plan* pl, const float* V, const float*
         launch_rowsplit_f<NFB, BORDER, false, 0>(rows, pl->count[WMF_BIN_GENERAL], V, biasv, indptr, indices, vals, f, ld, g, pl, st);
         return;
     }
-    if (normal > 0) launch_rowsplit_f<NFB, BORDER, true, 0>(rows, normal, V, biasv, indptr, indices, vals, f, ld, g, pl, st);
+    // ROUND 4: the first iter_count of the normal rows go to the matrix-free iteration kernel (wmf_iter.hip), which hands back what
+    // it does not solve as a device-side list (as in wmf_directw.hip); debug flag 268435456: off
+    const int64_t n_iter = biasv ? 0 : wmf_iter_rows(pl, f, ld, false);      // (biasv: always folded into vals by wmf_launch_solve)
+    if (n_iter > 0)
+        (void)wmf_launch_iter(rows, n_iter, V, nullptr, indptr, indices, vals, f, ld, g, pl->iter_bounce_rows, pl->fallback_count + 1,
+                              pl->iter_stats, st);
+    if (normal > n_iter) launch_rowsplit_f<NFB, BORDER, true, 0>(rows + n_iter, normal - n_iter, V, biasv, indptr, indices, vals, f, ld, g, pl, st);
+    if (n_iter > 0) launch_rowsplit_f<NFB, BORDER, true, 0>(pl->iter_bounce_rows, n_iter, V, biasv, indptr, indices, vals, f, ld, g, pl, st, pl->fallback_count + 1);
     if (pl->heavy_count > 0) {          // rows with more than WMF_HEAVY_T entries: segments by separate workgroups, then one combine each
         launch_rowsplit_f<NFB, BORDER, true, 1>(rows, pl->seg_total, V, biasv, indptr, indices, vals, f, ld, g, pl, st);
         wmf_launch_combine_segments(pl, RS_PARTIAL(NFB, BORDER), st);

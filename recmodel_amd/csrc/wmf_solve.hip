@@ -817,7 +817,7 @@ void wmf_launch_combine_segments(const wmf_plan* pl, int64_t partial_floats, hip
 int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
                      const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fail_count,
                      hipStream_t st) {
-    if (hipMemsetAsync(pl->fallback_count, 0, sizeof(int32_t), st) != hipSuccess) return -2;
+    if (hipMemsetAsync(pl->fallback_count, 0, 2 * sizeof(int32_t), st) != hipSuccess) return -2;   // [0] pivoted fallback, [1] rows bounced by wmf_iter.hip
     const int64_t nnz = pl->nnz[0] + pl->nnz[1] + pl->nnz[2] + pl->nnz[3];
     if (nnz == 0)                                                      // nothing stored: every row solves to zero
         return hipMemsetAsync(g, 0, (size_t)pl->n * ld * sizeof(float), st) == hipSuccess ? 0 : -2;
@@ -854,8 +854,18 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
         // 1024: the run-time-indexed eight-wave kernel (wmf_wide.hip)
         if (wmf_rowsplit_supported(f) && !(wmf_debug_flags & 1024)) {
             if (wmf_launch_rowsplit(pl, V, biasv, indptr, indices, vals, f, ld, g, st)) return -1;
-        } else if (wmf_launch_wide(pl->rows[WMF_BIN_GENERAL], pl->count[WMF_BIN_GENERAL], V, biasv, indptr, indices, vals, f, ld,
-                                   g, pl->fallback_rows, pl->fallback_count, st)) return -1;
+        } else {
+            // (f = 258 .. 272: no split rows; the iteration kernel first, as in wmf_directw.hip / wmf_rowsplit.hip)
+            const int32_t* rows = pl->rows[WMF_BIN_GENERAL];
+            const int64_t all = pl->count[WMF_BIN_GENERAL];
+            const int64_t n_iter = biasv ? 0 : wmf_iter_rows(pl, f, ld, false);
+            if (n_iter > 0 && wmf_launch_iter(rows, n_iter, V, nullptr, indptr, indices, vals, f, ld, g, pl->iter_bounce_rows,
+                                              pl->fallback_count + 1, pl->iter_stats, st)) return -1;
+            if (all > n_iter && wmf_launch_wide(rows + n_iter, all - n_iter, V, biasv, indptr, indices, vals, f, ld, g,
+                                                pl->fallback_rows, pl->fallback_count, st)) return -1;
+            if (n_iter > 0 && wmf_launch_wide(pl->iter_bounce_rows, n_iter, V, biasv, indptr, indices, vals, f, ld, g,
+                                              pl->fallback_rows, pl->fallback_count, st, pl->fallback_count + 1)) return -1;
+        }
     }
     {
         // rows bounced by the other kernels (negative weights / not positive definite); count is on the device

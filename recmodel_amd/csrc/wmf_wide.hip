@@ -51,7 +51,8 @@ __global__ __launch_bounds__(512, 1) void solve_wide_kernel(const int32_t* __res
                                                             const int32_t* __restrict__ indices,
                                                             const float* __restrict__ vals, int f, int ld,
                                                             float* __restrict__ g, int32_t* __restrict__ fb_rows,
-                                                            int32_t* __restrict__ fb_count, int dbg) {
+                                                            int32_t* __restrict__ fb_count, int dbg, const int32_t* __restrict__ count_dev) {
+    if (count_dev) count = *count_dev;                           // (the rows the iteration kernel bounced: the count is on the device)
     using C = WideCfg<NFB>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256) void solve_wide_lu_kernel(const int32_t* __res
 template <int NFB>
 static void launch_wide_nfb(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                             const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
-                            int32_t* fb_count, hipStream_t st) {
+                            int32_t* fb_count, hipStream_t st, const int32_t* count_dev) {
     using C = WideCfg<NFB>;
     constexpr size_t lds = (size_t)C::TOTAL * 4;
     static bool attr_set = false;
@@ -370,18 +371,19 @@ static void launch_wide_nfb(const int32_t* rows, int64_t count, const float* V, 
     int64_t grid = 256 * 2;                                      // one resident workgroup per CU (LDS), two rounds
     if (grid > count) grid = count;
     static const char* nm = wmf_kname("solve_wide_kernel<%d>", NFB);
-    WMF_LAUNCH(nm, (solve_wide_kernel<NFB>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, rows, count, V, biasv, indptr,
-               indices, vals, f, ld, g, fb_rows, fb_count, wmf_debug_flags);
+    static const char* nmb = wmf_kname("solve_wide_kernel<%d> [bounced]", NFB);
+    WMF_LAUNCH(count_dev ? nmb : nm, (solve_wide_kernel<NFB>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, rows, count, V, biasv, indptr,
+               indices, vals, f, ld, g, fb_rows, fb_count, wmf_debug_flags, count_dev);
 }
 
 int wmf_wide_supported(int f) { return f > 144 && f <= 272; }
 
 int wmf_launch_wide(const int32_t* rows, int64_t count, const float* V, const float* biasv, const int64_t* indptr,
                     const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fb_rows,
-                    int32_t* fb_count, hipStream_t st) {
+                    int32_t* fb_count, hipStream_t st, const int32_t* count_dev) {
     if (count <= 0) return 0;
     switch ((f + 15) / 16) {
-#define C_(N) case N: launch_wide_nfb<N>(rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, st); break;
+#define C_(N) case N: launch_wide_nfb<N>(rows, count, V, biasv, indptr, indices, vals, f, ld, g, fb_rows, fb_count, st, count_dev); break;
         C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16) C_(17)
 #undef C_
         default: return -1;

@@ -105,9 +105,16 @@ class HipKernels:
     def plan_create(self, indptr_host, n, f, bias):
         handle = ctypes.c_void_p()
         _lib.check(self.lib.wmf_plan_create(indptr_host.ctypes.data_as(ctypes.c_void_p), n, f, int(bool(bias)), ctypes.byref(handle)))
-        stats = np.zeros(12, dtype=np.int64)
+        stats = np.zeros(14, dtype=np.int64)
         _lib.check(self.lib.wmf_plan_stats(handle, stats.ctypes.data_as(ctypes.c_void_p)))
         return handle, stats
+
+    def plan_iter_stats(self, handle):
+        """(rows solved by the matrix-free iteration, rows it handed back to the elimination kernels, applications of the row
+        operator, rows on the Chebyshev recurrence) since the last call; synchronises the device."""
+        out = np.zeros(4, dtype=np.int64)
+        _lib.check(self.lib.wmf_plan_iter_stats(handle, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
 
     def plan_destroy(self, handle):
         self.lib.wmf_plan_destroy(handle)
@@ -195,6 +202,15 @@ class Csr:
         self.bin_rows, self.bin_nnz = stats[:4].copy(), stats[4:8].copy()
         self.rows8, self.nnz8 = int(stats[8]), int(stats[9])           # rows of bin 0 with at most 8 entries
         self.rows_split, self.nnz_split = int(stats[10]), int(stats[11])   # rows of bin 2 split over several waves
+        # rows (of bin 2 / 3) short enough for the matrix-free iteration kernel, csrc/wmf_iter.hip
+        self.rows_iter, self.nnz_iter = (int(stats[12]), int(stats[13])) if len(stats) > 13 else (0, 0)
+
+    def iter_stats(self):
+        """What the iteration kernel did with its candidates since the last call (see HipKernels.plan_iter_stats); zeros for
+        a back end without it."""
+        if self._plan is None or not hasattr(self.kernels, "plan_iter_stats"):
+            return np.zeros(4, dtype=np.int64)
+        return self.kernels.plan_iter_stats(self._plan)
 
     def __del__(self):
         plan, self._plan = getattr(self, "_plan", None), None

@@ -70,7 +70,7 @@ class NumpyKernels:
 
     def plan_create(self, indptr_host, n, f, bias=False):
         deg = np.diff(indptr_host)
-        stats = np.zeros(12, dtype=np.int64)
+        stats = np.zeros(14, dtype=np.int64)
         stats[0], stats[4] = n, deg.sum()
         return ("plan", n, f), stats
 

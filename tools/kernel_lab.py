@@ -8,13 +8,16 @@ from recmodel_amd import _lib, synth
 from recmodel_amd.engine import AlsEngine, _ptr, _stream
 from recmodel_amd import WMF
 
+import os
+ZIPF = float(os.environ.get("LAB_ZIPF", "0"))          # item popularity exponent (0 = uniform)
+HIST = os.environ.get("LAB_HIST") == "1"               # print the distribution of tr E = sum_e w_e |v_e|^2 over the side's rows
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 side = sys.argv[2] if len(sys.argv) > 2 else "items"
 flags = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "0").split(",")]
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 lib = _lib.load()
 n_users, n_items, dbar, k, bias = synth.CONFIGS[cfg]
-ip, idx, val = synth.make_counts(n_users, n_items, dbar, 1995, device="cuda")
+ip, idx, val = synth.make_counts(n_users, n_items, dbar, 1995, device="cuda", zipf_a=ZIPF)
 val = 10 * torch.log(1 + val)
 eng = AlsEngine(n_users, n_items, k, bias, 0.1)
 eng.set_interactions(ip, idx, val)
@@ -24,7 +27,32 @@ torch.cuda.synchronize()
 fixed = eng._other(side)
 eng.prepare(fixed)
 c = eng.csr[side]
-print(f"{cfg} side={side} rows={c.n_rows} nnz={c.nnz} f={eng.f} bins rows={c.bin_rows.tolist()} nnz={c.bin_nnz.tolist()}")
+print(f"{cfg} zipf={ZIPF} side={side} rows={c.n_rows} nnz={c.nnz} f={eng.f} bins rows={c.bin_rows.tolist()} nnz={c.bin_nnz.tolist()} "
+      f"iteration candidates: rows={c.rows_iter} nnz={c.nnz_iter}")
+if HIST:
+    # tr E of every row: the bound the iteration kernel (csrc/wmf_iter.hip) decides on.  Whitened rows: the packed body, plus
+    # the border feature of the split layout (first float of the pairs); weights: minus the fixed side's bias there.
+    V = eng.V[fixed]
+    n2 = (V.double() ** 2).sum(1)
+    w = c.values.double()
+    if bias and eng.split:
+        n2 = n2 + eng.bias_vec[fixed][:, 0].double() ** 2
+        w = w - eng.bias_vec[fixed][:, 1].double()[c.indices.long()]
+    elif bias:
+        w = w - eng.bias_vec[fixed].double()[c.indices.long()]
+    deg = c.indptr[1:] - c.indptr[:-1]
+    rows_of = torch.repeat_interleave(torch.arange(c.n_rows, device=w.device), deg)
+    contrib = w * n2[c.indices.long()]
+    tau_p = torch.zeros(c.n_rows, dtype=torch.float64, device=w.device).index_add_(0, rows_of, contrib.clamp_min(0))
+    tau_n = torch.zeros(c.n_rows, dtype=torch.float64, device=w.device).index_add_(0, rows_of, (-contrib).clamp_min(0))
+    for name, sel in (("rows with 33+ entries", deg > 32), ("rows with <= 32 entries", (deg > 0) & (deg <= 32))):
+        if int(sel.sum()) == 0:
+            continue
+        t = tau_p[sel]
+        qs = torch.quantile(t[torch.randperm(t.numel(), device=t.device)[:2_000_000]], torch.tensor([0.01, 0.5, 0.9, 0.99, 0.999, 1.0], dtype=torch.float64, device=t.device))
+        print(f"  tr E, {name} ({int(sel.sum())}): q01 {qs[0]:.3g}  median {qs[1]:.3g}  q90 {qs[2]:.3g}  q99 {qs[3]:.3g}  q99.9 {qs[4]:.3g}  max(sample) {qs[5]:.3g};"
+              f"  share <= 0.06: {float((t <= 0.06).double().mean()):.4f}, <= 0.5: {float((t <= 0.5).double().mean()):.4f}, <= 3: {float((t <= 3).double().mean()):.4f};"
+              f"  negative part max {float(tau_n[sel].max()):.3g}")
 for fl in flags:
     lib.wmf_debug_set_flags(fl)
     lib.wmf_profile_enable(0)
@@ -39,6 +67,10 @@ for fl in flags:
     torch.cuda.synchronize()
     lib.wmf_profile_enable(0)
     print(f"flags={fl}: " + ", ".join(f"{nm}={ms / reps:.3f}ms/{n // reps}" for nm, _, ms, n, _, _ in _lib.profile_table(lib)))
+    st = c.iter_stats() // max(1, reps + 2)
+    if st.sum():
+        print(f"    iteration kernel per launch: solved {st[0]}, handed back {st[1]}, applications of E per solved row "
+              f"{st[2] / max(1, st[0]):.2f}, on the Chebyshev recurrence {st[3]}")
     lib.wmf_profile_reset()
     gnow = eng.g[side].clone()
     if fl == flags[0]:
