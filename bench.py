@@ -146,6 +146,12 @@ def kernel_work(name, csr, eng, side):
         return "hbm", (nnz[0] - csr.nnz8) * ent_b + (rows[0] - csr.rows8) * row_b
     if name.startswith("solve_low_kernel"):
         return "hbm", nnz[1] * ent_b + rows[1] * row_b
+    if name.endswith("[bounced]"):
+        return None       # the elimination kernels over the rows the iteration kernel handed back: a device-side list, no model here
+    if name.startswith("solve_iter_kernel"):
+        # every candidate row is gathered once by this kernel (the rows it hands back are gathered again by the elimination
+        # kernels; that second gather is not algorithmic)
+        return "hbm", csr.nnz_iter * ent_b + csr.rows_iter * row_b
     m = re.match(r"solve_(directl|directw|rowsplit|wide)_kernel<([^>]*)>", name)
     if m:
         # MODE of the launch: 0 = whole rows (everything of the bin that is not split), 1 = the 2048-entry segments of the
@@ -155,8 +161,9 @@ def kernel_work(name, csr, eng, side):
         kind = m.group(1)
         mode = int(targs[1]) if kind == "directw" else (int(targs[-1]) if kind in ("directl", "rowsplit") else 0)
         b = 2 if kind in ("directl", "directw") else 3
-        if mode == 0:
-            return "hbm", (nnz[b] - csr.nnz_split) * ent_b + (rows[b] - csr.rows_split) * row_b
+        if mode == 0:             # (the rows that were never candidates of the iteration kernel)
+            it_rows, it_nnz = (csr.rows_iter, csr.nnz_iter) if eng.iter_on else (0, 0)
+            return "hbm", (nnz[b] - csr.nnz_split - it_nnz) * ent_b + (rows[b] - csr.rows_split - it_rows) * row_b
         if mode == 1:
             return "hbm", csr.nnz_split * ent_b
         return None
@@ -283,6 +290,8 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu, zipf=
         step()
     barrier()
     eng.check_numerics()
+    for s_ in SIDES:
+        eng.iter_stats(s_)                          # (clears the counters of the warm-up iterations)
     lib.wmf_profile_reset()
     lib.wmf_profile_enable(1)
     barrier()
@@ -295,6 +304,16 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu, zipf=
     eng.check_numerics()
     table = _lib.profile_table(lib)
     lib.wmf_profile_reset()
+    # what the matrix-free iteration kernel did with its candidates in the timed iterations (data dependent: see csrc/wmf_iter.hip)
+    paths = {}
+    for s_ in SIDES:
+        st = eng.iter_stats(s_)
+        cand = int(st[0] + st[1])
+        if cand:
+            n_rows = max(1, eng.n_local[s_]) * args.steps
+            paths[s_] = {"iterated_share_of_rows": round(float(st[0]) / n_rows, 4), "handed_back_share_of_rows": round(float(st[1]) / n_rows, 6),
+                         "applications_per_iterated_row": round(float(st[2]) / max(1, int(st[0])), 2),
+                         "chebyshev_share_of_iterated": round(float(st[3]) / max(1, int(st[0])), 4)}
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -355,6 +374,8 @@ def run_workload(cfg_name, args, world, rank, dev, lib, scaling, with_cpu, zipf=
         if "mfma_issue" in dom:
             roofline["hbm_floor_ms"] = dom["hbm_floor_ms"]
             roofline["mfma_issue"] = dom["mfma_issue"]
+        if paths:
+            roofline["paths"] = paths
     # the north star's named target: the per-user solve (every row kernel of the users half step together)
     half = {}
     for s in SIDES:

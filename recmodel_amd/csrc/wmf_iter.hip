@@ -102,6 +102,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
             const int e = EPS * s + 4 * wv + q;
             id[s] = indices[l + (e < dd ? e : 0)];      // (unconditional: a select against a constant would make the register
                                                         // write wait for every request in flight; entry 0 again is an L1 hit)
+#ifdef IT_LAB_SAMEROWS                                  // lab: every row gathers the same few rows (cache hits): the kernel without its
+            id[s] &= 1023;                              // memory latency (results are those of a different matrix)
+#endif
         }
     };
     // (the first row's ids go through LDS like every later row's: one code path, and no request of the row loop ever waits on
@@ -457,21 +460,26 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
 #define IT_OCC4S 2            // (three workgroups per CU spill the pairs: a scratch store of a loaded value waits for the load)
 #endif
 static int it_ldv(int f, int ld, bool split) { return split ? f - 1 : ld; }
+static float it_env(const char* name, float dflt) {
+    const char* s = getenv(name);
+    return s && *s ? (float)atof(s) : dflt;
+}
 
 // rows of up to this many entries are candidates (0: no kernel for this width)
 int wmf_iter_dmax(int f, int ld, int split) {
     const int ldv = it_ldv(f, ld, split != 0);
     if (split && ldv > 128) return 0;
+    // Narrow factors stay with the elimination kernels by default: at 4 features per lane the sums over the lanes of an entry
+    // cost as much as its multiply-adds, and the f x f elimination is cheap -- measured on MI355X at k = 64 (BASELINE.json
+    // configs[1], item rows of 200 entries, four applications of E): 1.17 ms against 1.05 ms for solve_directl.
+    // WMF_ITER_MIN_LDV = 0 sends them here as well.
+    static const int min_ldv = (int)it_env("WMF_ITER_MIN_LDV", 65.f);
+    if (ldv < min_ldv) return 0;
     if (ldv <= 64) return 16 * (split ? IT_NS64S : IT_NS64);
     if (ldv <= 128) return 16 * (split ? IT_NS128S : IT_NS128);
     if (ldv <= 256) return 32 * 8;
     if (ldv <= 320) return 32 * 6;
     return 0;
-}
-
-static float it_env(const char* name, float dflt) {
-    const char* s = getenv(name);
-    return s && *s ? (float)atof(s) : dflt;
 }
 
 template <int NW, int FPL, int NS, bool SPLIT, bool FULL, int OCC>
@@ -486,7 +494,7 @@ static void it_launch(const int32_t* rows, int64_t count, const float* V, const 
     // at most WMF_ITER_KMAX applications of E
     static const float tau_n = it_env("WMF_ITER_TAU", 0.8f), kap = it_env("WMF_ITER_KAPPA", 4.f);
     static const int kmax = (int)it_env("WMF_ITER_KMAX", 20.f);
-    static const float eps = it_env("WMF_ITER_EPS", 6e-8f);      // relative accuracy of a solved row (float32 rounding)
+    static const float eps = it_env("WMF_ITER_EPS", 1.2e-7f);     // relative accuracy of a solved row: 2^-23, one float32 ulp
     const int64_t resident = 256LL * (OCC * 4 / NW);              // workgroups the chip holds
     const int64_t cap = resident * 4;                            // four rounds queued: rows differ in length
     WMF_LAUNCH(nm, (solve_iter_kernel<NW, FPL, NS, SPLIT, FULL, OCC>), dim3((unsigned)(count < cap ? count : cap)), dim3(64 * NW), 0, st,

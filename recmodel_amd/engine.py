@@ -987,6 +987,18 @@ class AlsEngine:
         for c in range(len(self.chunk_bounds[side])):
             self._publish(side, c)
 
+    iter_on = True      # the matrix-free iteration kernel (csrc/wmf_iter.hip) is part of the solve; tools that switch it off with
+                        # wmf_debug_set_flags(268435456) set this to False for bench.py's byte model
+
+    def iter_stats(self, side):
+        """(rows solved by the matrix-free iteration, rows it handed back to the elimination kernels, applications of the row
+        operator, rows on the Chebyshev recurrence) over the half steps of ``side`` since the last call, summed over the
+        chunks; synchronises the device."""
+        out = np.zeros(4, dtype=np.int64)
+        for c in self.csr_chunks.get(side, []):
+            out += c.iter_stats()
+        return out
+
     def check_numerics(self):
         """Host sync: raise if a Gramian was not positive definite or a row system was singular (the reference's
         np.linalg.solve raises LinAlgError there).  The two flags are sticky on the device, so one check per iteration
