@@ -276,6 +276,20 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, int bias, wmf_plan*
     if (e == hipSuccess && bias && !p->split && nnz_all > 0) e = hipMalloc((void**)&p->w_eff, (size_t)nnz_all * sizeof(float));
     if (e == hipSuccess && f > 144) e = hipMalloc((void**)&p->wide_ws, wmf_wide_lu_workspace_bytes(f));
     if (e == hipSuccess && p->iter_count > 0) e = hipMalloc((void**)&p->iter_bounce_rows, (size_t)p->iter_count * sizeof(int32_t));
+    if (e == hipSuccess && p->iter_count > 0) {
+        // the candidates' bookkeeping as one 16-byte record per row (the iteration kernel reads it with one scalar load)
+        const int32_t* cand = order.data() + start[hb];
+        std::vector<int32_t> rec((size_t)p->iter_count * 4);
+        for (int64_t i = 0; i < p->iter_count; ++i) {
+            const int64_t lo = indptr[cand[i]];
+            rec[(size_t)4 * i] = (int32_t)(uint32_t)(lo & 0xffffffffLL);
+            rec[(size_t)4 * i + 1] = (int32_t)(uint32_t)((uint64_t)lo >> 32);
+            rec[(size_t)4 * i + 2] = cand[i];
+            rec[(size_t)4 * i + 3] = (int32_t)(indptr[cand[i] + 1] - lo);
+        }
+        e = hipMalloc((void**)&p->iter_info, rec.size() * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMemcpy(p->iter_info, rec.data(), rec.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess && p->iter_count > 0) e = hipMalloc((void**)&p->iter_stats, 4 * sizeof(unsigned long long));
     if (e == hipSuccess && p->iter_count > 0) e = hipMemset(p->iter_stats, 0, 4 * sizeof(unsigned long long));
     if (e == hipSuccess && p->heavy_count > 0) {
@@ -308,6 +322,7 @@ void wmf_plan_destroy(wmf_plan* p) {
     if (p->wide_ws) (void)hipFree(p->wide_ws);
     if (p->iter_bounce_rows) (void)hipFree(p->iter_bounce_rows);
     if (p->iter_stats) (void)hipFree(p->iter_stats);
+    if (p->iter_info) (void)hipFree(p->iter_info);
     if (p->seg_lo) (void)hipFree(p->seg_lo);
     if (p->seg_d) (void)hipFree(p->seg_d);
     if (p->seg_first) (void)hipFree(p->seg_first);

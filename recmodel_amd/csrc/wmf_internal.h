@@ -39,6 +39,7 @@ struct wmf_plan {
     int64_t iter_count, iter_nnz;
     int iter_dmax;             // the candidates' longest admissible row at the width / layout the plan was created for
     int32_t* iter_bounce_rows; // device: iter_count slots
+    int32_t* iter_info;        // device: iter_count x {first entry (low, high word), row id, entries}: a candidate's bookkeeping in one 16-byte load
     unsigned long long* iter_stats;   // device: 4 counters, accumulated over the launches (wmf_plan_iter_stats reads and clears)
 };
 
@@ -99,7 +100,7 @@ int wmf_launch_wide(const int32_t* rows, int64_t count, const float* V, const fl
 int wmf_iter_dmax(int f, int ld, int split);
 int wmf_launch_iter(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
                     const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* bounce_rows,
-                    int32_t* bounce_count, unsigned long long* stats, hipStream_t st);
+                    int32_t* bounce_count, unsigned long long* stats, const void* info, hipStream_t st);
 static inline bool wmf_iter_enabled() { return !(wmf_debug_flags & 268435456); }
 // candidates of this call: none when the iteration is switched off, or when the call's layout (ld, split) is not the one the
 // plan sorted its rows for (a caller with its own leading dimension: the kernel's register slots would not hold the rows)

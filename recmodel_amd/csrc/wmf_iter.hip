@@ -59,20 +59,63 @@ struct ItLds {
 // counters of a launch (per plan, wmf_plan_iter_stats): rows solved here, rows bounced, applications of E in total
 enum { IT_STAT_DONE = 0, IT_STAT_BOUNCED = 1, IT_STAT_APPLICATIONS = 2, IT_STAT_CHEB = 3 };
 
+
+// ---- LDS access the compiler does not see (DMA variant): while an LDS-DMA (global_load_lds) may be outstanding hipcc puts
+// s_waitcnt vmcnt(0) in front of every LDS access it knows of, which would stall each exchange of the iteration behind the
+// prefetch of the next row.  Every LDS read / write of that variant is therefore inline asm with hand-placed waits.
+typedef const __attribute__((address_space(1))) void* it_gptr;
+typedef __attribute__((address_space(3))) void* it_lptr;
+template <int OFF>
+__device__ __forceinline__ void it_ds_write32(unsigned addr, float v) {
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ f32x4 it_ds_read128(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ float it_ds_read32(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// every outstanding LDS operation has returned; the values pass through the wait, so no use of them can move above it
+// f(integral_constant<int, 0>) .. f(integral_constant<int, N - 1>): loops whose index must be a compile-time constant (immediates)
+template <int N, class F>
+__device__ __forceinline__ void it_for(F&& f) {
+    [&]<int... Is>(std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
+#define IT_I(X) decltype(X)::value
+__device__ __forceinline__ void it_lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void it_tie(f32x4& a) { asm volatile("" : "+v"(a)::"memory"); }
+__device__ __forceinline__ void it_tie(float& a) { asm volatile("" : "+v"(a)::"memory"); }
+
 // FULL: every lane's pieces lie inside a row (16 FPL floats per gathered row exactly: k = 64, 128, 256 with or without the
 // split layout's border) -- no piece masks in the gather.
-template <int NW, int FPL, int NS, bool SPLIT, bool FULL, int OCC>
+// DMA (four waves, FULL): the NEXT row's gathered rows, weights and border / bias values are fetched into an LDS region of the
+// workgroup by LDS-DMA while this row is iterated on -- no registers, no wait until the row switch, where a wave copies its
+// own entries from LDS to registers.  Without it a row switch exposes one memory latency per row (measured at configs[2]:
+// 13.5 ms, of which 3 ms go when every gather hits the cache).
+template <int NW, int FPL, int NS, bool SPLIT, bool FULL, int OCC, bool DMA>
 __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                                  const float* __restrict__ V, const float* __restrict__ side,
                                                                  const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                                  const float* __restrict__ vals, int f, int ld, float* __restrict__ g,
                                                                  int32_t* __restrict__ bounce_rows, int32_t* __restrict__ bounce_count,
                                                                  float tau_neumann, float kappa_max, int kmax, float eps2,
-                                                                 unsigned long long* __restrict__ stats) {
+                                                                 unsigned long long* __restrict__ stats, const int4* __restrict__ info) {
     constexpr int H = FPL / 2, P4 = FPL / 4, EPS = 4 * NW;
     using L = ItLds<NW, FPL>;
-    __shared__ __attribute__((aligned(16))) float lds[L::EXCH];
-    __shared__ int next_ids[NS][64 * NW];               // the next row's column ids wait here, not in registers
+    static_assert(!DMA || (NW == 4 && FULL), "DMA variant: four waves, whole pieces");
+    // DMA: [exchange buffers | ring: wave, slot, piece -> 1 KB (lane l at 16 l) | meta: wave -> weights, border, bias (64 dwords each)]
+    constexpr int RING_OFF = L::EXCH * 4, META_OFF = RING_OFF + NW * NS * P4 * 1024;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    __shared__ __attribute__((aligned(16))) float lds_static[DMA ? 4 : L::EXCH];
+    __shared__ int next_ids[DMA ? 1 : NS][DMA ? 1 : 64 * NW];               // (no DMA) the next row's column ids wait here, not in registers
+    float* lds = DMA ? reinterpret_cast<float*>(dyn_lds) : lds_static;
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)dyn_lds);   // LDS byte address (DMA variant)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -91,10 +134,19 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
     int u = 0, d = 0;
     int64_t lo = 0;
     int idx[NS];
+    // row i of the list: {first entry (two words), row id, entries} -- ONE 16-byte scalar load from the plan's table (info) where
+    // rows[i] -> indptr[u], indptr[u + 1] are two dependent ones; requested two rows ahead, so no row waits on it
     auto row_of = [&](int64_t i, int& uu, int64_t& l, int& dd) {
-        uu = rows[i];
-        l = indptr[uu];
-        dd = (int)(indptr[uu + 1] - l);
+        if (info) {
+            const int4 ri = info[i];
+            l = (int64_t)(((unsigned long long)(unsigned)ri.y << 32) | (unsigned)ri.x);
+            uu = ri.z;
+            dd = ri.w;
+        } else {
+            uu = rows[i];
+            l = indptr[uu];
+            dd = (int)(indptr[uu + 1] - l);
+        }
     };
     auto fetch_ids = [&](int64_t l, int dd, int (&id)[NS]) {
 #pragma unroll
@@ -107,20 +159,80 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
 #endif
         }
     };
-    // (the first row's ids go through LDS like every later row's: one code path, and no request of the row loop ever waits on
-    // a load that was issued outside it)
+    // DMA variant: the requests of one row (l, dd) with the column ids id[] (slot layout) and idm (meta layout: lane l < 4 NS is
+    // entry 4 NW (l >> 2) + 4 w + (l & 3)): per slot in use P4 instructions of 64 x 16 bytes, then one dword instruction for the
+    // weights and two for the {border, bias} pairs.  Destinations are wave uniform (M0); a lane's data lands at 16 l / 4 l.
+    auto issue_dma = [&](int64_t l, int dd, const int (&id)[NS], int idm) {
+        if constexpr (DMA) {
+            const int nsn = (dd + EPS - 1) / EPS;
+            // every id is read here, once, before the first request: the compiler then waits for the id loads now -- left to
+            // itself it waits in front of each slot's address arithmetic, and as the requests of the slots before are younger
+            // than the id loads and conditional, that wait is vmcnt(0): each slot's fetch would complete before the next is issued
+            int idl[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { idl[s] = id[s]; asm volatile("" : "+v"(idl[s])); }
+            asm volatile("" : "+v"(idm));
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s < nsn) {
+                    const float* row = V + (int64_t)idl[s] * ldv + r * FPL;
+#pragma unroll
+                    for (int j = 0; j < P4; ++j)
+                        __builtin_amdgcn_global_load_lds((it_gptr)(row + 4 * j), (it_lptr)(dyn_lds + RING_OFF + ((wv * NS + s) * P4 + j) * 1024), 16, 0, 0);
+                }
+            }
+            if (lane < 4 * NS) {
+                const int e = EPS * (lane >> 2) + 4 * wv + (lane & 3);
+                __builtin_amdgcn_global_load_lds((it_gptr)(vals + l + (e < dd ? e : 0)), (it_lptr)(dyn_lds + META_OFF + wv * 768), 4, 0, 0);
+                if constexpr (SPLIT) {
+                    __builtin_amdgcn_global_load_lds((it_gptr)(side + 2 * (int64_t)idm), (it_lptr)(dyn_lds + META_OFF + wv * 768 + 256), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((it_gptr)(side + 2 * (int64_t)idm + 1), (it_lptr)(dyn_lds + META_OFF + wv * 768 + 512), 4, 0, 0);
+                }
+            }
+        }
+    };
+    auto fetch_idm = [&](int64_t l, int dd) {           // the id of this lane's entry in the meta layout
+        const int e = EPS * (lane >> 2) + 4 * wv + (lane & 3);
+        int v = indices[l + ((lane < 4 * NS && e < dd) ? e : 0)];
+#ifdef IT_LAB_SAMEROWS
+        v &= 1023;
+#endif
+        return v;
+    };
+    // Pipeline of the bookkeeping (G = gridDim.x rows apart).  Without DMA: row i's trip requests the ids of row i + G and the
+    // record of row i + 2 G.  With DMA everything moves one row further ahead, so that the fetch of row i + G can be requested
+    // as soon as row i has been copied out of the ring, a whole row before it is needed: the trip of row i holds the ids of row
+    // i + G (idp / idmp, loaded during the trip before), requests those of row i + 2 G and the record of row i + 3 G.
+    const int64_t G = gridDim.x;
+    int un = 0, dn = 0, unn = 0, dnn = 0;               // the records of the next two rows
+    int64_t lon = 0, lonn = 0;
+    int idp[NS], idmp = 0;                              // DMA: ids of the next row, carried across the trip
+    if (it + G < count) row_of(it + G, un, lon, dn);
+    if (DMA && it + 2 * G < count) row_of(it + 2 * G, unn, lonn, dnn);
     if (it < count) {
         row_of(it, u, lo, d);
         fetch_ids(lo, d, idx);
+        if constexpr (DMA) {
+            issue_dma(lo, d, idx, SPLIT ? fetch_idm(lo, d) : 0);
+            if (it + G < count) {
+                fetch_ids(lon, dn, idp);
+                if constexpr (SPLIT) idmp = fetch_idm(lon, dn);
+            }
+        } else {
+            // (the first row's ids go through LDS like every later row's: one code path, and no request of the row loop ever
+            // waits on a load that was issued outside it)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) next_ids[s][threadIdx.x] = idx[s];
+            for (int s = 0; s < NS; ++s) next_ids[s][threadIdx.x] = idx[s];
+        }
     }
 
     for (; it < count; it += gridDim.x) {
         const int ns = (d + EPS - 1) / EPS;             // slots in use (wave uniform)
         const int ns4 = (ns + 3) & ~3;                  // ... rounded up to the groups of four the passes work in
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) idx[s] = next_ids[s][threadIdx.x];
+            for (int s = 0; s < NS; ++s) idx[s] = next_ids[s][threadIdx.x];
+        }
         // ---- gather: REQUESTS ONLY (nothing in this loop reads what it loads, so no wait separates the slots' requests):
         // body pieces, weight, border / bias pair of every entry of this wave
         it_f32x2 vb[NS][H], pr[NS];
@@ -135,6 +247,34 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
                 pr[s] = it_f32x2{0.f, 0.f};
             }
         }
+        if constexpr (DMA) {
+            // the row was fetched into LDS while the previous one was iterated on: every DMA of this wave has landed after the
+            // wait; a lane copies its own 16-byte pieces and its group's weight / border / bias to registers
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned ring_rd = lds0 + RING_OFF + wv * NS * P4 * 1024 + lane * 16;
+            const unsigned meta_rd = lds0 + META_OFF + wv * 768 + q * 4;
+            it_for<NS>([&](auto S) {
+                constexpr int s = IT_I(S);
+                if (s < ns) {
+                    it_for<P4>([&](auto J) {
+                        constexpr int j = IT_I(J);
+                        const f32x4 piece = it_ds_read128<(s * P4 + j) * 1024>(ring_rd);
+                        vb[s][2 * j] = it_f32x2{piece[0], piece[1]};
+                        vb[s][2 * j + 1] = it_f32x2{piece[2], piece[3]};
+                    });
+                    wt[s] = it_ds_read32<16 * s>(meta_rd);
+                    if constexpr (SPLIT) pr[s] = it_f32x2{it_ds_read32<256 + 16 * s>(meta_rd), it_ds_read32<512 + 16 * s>(meta_rd)};
+                }
+            });
+            it_lgkm_wait();
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                for (int j = 0; j < H; ++j) asm volatile("" : "+v"(vb[s][j])::"memory");
+                it_tie(wt[s]);
+                if constexpr (SPLIT) asm volatile("" : "+v"(pr[s])::"memory");
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (s < ns) {
@@ -150,15 +290,84 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
                 if constexpr (SPLIT) pr[s] = *reinterpret_cast<const it_f32x2*>(side + 2 * (int64_t)idx[s]);
             }
         }
-        // the row after this one: ids requested now, parked in LDS behind pass 0, used at the next trip
-        const int64_t itn = it + gridDim.x;
-        int un = 0, dn = 0;
-        int64_t lon = 0;
-        int idn[NS];
-        if (itn < count) { row_of(itn, un, lon, dn); fetch_ids(lon, dn, idn); }
+        }
+        const int64_t itn = it + G;
+        int idn[NS], idmn = 0;
+        int u3 = 0, d3 = 0;                                 // the record requested in this trip
+        int64_t lo3 = 0;
+        if constexpr (DMA) {
+            // the ring is free (this wave's copies to registers have returned): the NEXT row's fetch starts here and has the whole
+            // of this row's passes to land.  (The ids are read unconditionally first: their loads sat under a test like the
+            // requests do, but the compiler does not correlate the two, and on the path "loaded, not requested" that it sees the
+            // id registers would still be in flight at the join -- where the first instruction to reuse one got an
+            // s_waitcnt vmcnt(0), i.e. a wait for the whole prefetch right behind its issue.)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(idp[s]));
+            asm volatile("" : "+v"(idmp));
+            if (itn < count) issue_dma(lon, dn, idp, idmp);
+            // ids of the row after the next, record of the one after that
+            if (itn + G < count) {
+                fetch_ids(lonn, dnn, idn);
+                if constexpr (SPLIT) idmn = fetch_idm(lonn, dnn);
+            }
+            if (itn + 2 * G < count) row_of(itn + 2 * G, u3, lo3, d3);
+        } else {
+            // the row after this one: ids requested now, parked in LDS behind pass 0, used at the next trip
+            if (itn < count) fetch_ids(lon, dn, idn);
+            if (itn + G < count) row_of(itn + G, u3, lo3, d3);
+        }
 
         // ---- one exchange: z (feature partials of this wave's entries) and NSC scalars -> totals over the row --------------
         auto exchange = [&]<int NSC>(std::integral_constant<int, NSC>, it_f32x2 (&z)[H], float& zb, float& s1, float& s2) {
+            if constexpr (DMA) {
+                // the same exchange with every LDS access in inline asm (see it_ds_write32): byte addresses, immediates for the
+                // piece / wave offsets, lgkmcnt waits by hand, a bare s_barrier (no fence: nothing but LDS is shared)
+                constexpr int BUF = (L::VEC + NW * 4) * 4;
+                const unsigned base = lds0 + parity * BUF;
+                const unsigned wr = base + (wv * L::FEAT + r * FPL + q) * 4, scw = base + L::VEC * 4 + (wv * 4 + q) * 4;
+                const unsigned rd = base + r * FPL * 4, scr = base + L::VEC * 4;
+                it_for<P4>([&](auto J) {
+                    constexpr int j = IT_I(J);
+                    it_ds_write32<16 * j>(wr, it_rs4(z[2 * j][0], z[2 * j][1], z[2 * j + 1][0], z[2 * j + 1][1]));
+                });
+                if constexpr (NSC > 0) {
+                    const float tsc = NSC > 1 ? it_rs4(zb, s1, s2, 0.f) : wmf_qsum(zb);
+                    if (r == 0 && (NSC > 1 || q == 0)) it_ds_write32<0>(scw, tsc);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                f32x4 part[NW][P4], sacc[NW];
+                float sac1[NW];
+                it_for<NW>([&](auto W) {
+                    constexpr int w2 = IT_I(W);
+                    it_for<P4>([&](auto J) {
+                        constexpr int j = IT_I(J);
+                        part[w2][j] = it_ds_read128<(w2 * L::FEAT + 4 * j) * 4>(rd);
+                    });
+                    if constexpr (NSC > 1) sacc[w2] = it_ds_read128<16 * w2>(scr);
+                    else if constexpr (NSC == 1) sac1[w2] = it_ds_read32<16 * w2>(scr);
+                });
+                it_lgkm_wait();
+#pragma unroll
+                for (int w2 = 0; w2 < NW; ++w2) {
+#pragma unroll
+                    for (int j = 0; j < P4; ++j) it_tie(part[w2][j]);
+                    if constexpr (NSC > 1) it_tie(sacc[w2]);
+                    else if constexpr (NSC == 1) it_tie(sac1[w2]);
+                }
+#pragma unroll
+                for (int w2 = 1; w2 < NW; ++w2) {                // (a fixed order: wave 0, 1, ..)
+#pragma unroll
+                    for (int j = 0; j < P4; ++j) part[0][j] += part[w2][j];
+                    if constexpr (NSC > 1) sacc[0] += sacc[w2];
+                    else if constexpr (NSC == 1) sac1[0] += sac1[w2];
+                }
+#pragma unroll
+                for (int j = 0; j < P4; ++j) { z[2 * j] = it_f32x2{part[0][j][0], part[0][j][1]}; z[2 * j + 1] = it_f32x2{part[0][j][2], part[0][j][3]}; }
+                if constexpr (NSC > 1) { zb = sacc[0][0]; s1 = sacc[0][1]; s2 = sacc[0][2]; }
+                else if constexpr (NSC == 1) zb = sac1[0];
+                parity ^= 1;
+                return;
+            }
             float* vec = lds + parity * (L::VEC + NW * 4);
             float* sc = vec + L::VEC;
 #pragma unroll
@@ -303,9 +512,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
         }
         tp = wmf_row16_sum(tp);
         tn = wmf_row16_sum(tn);
-        if (itn < count) {                                  // (the ids have landed behind the rows of pass 0)
+        if constexpr (!DMA) {
+            if (itn < count) {                              // (the ids have landed behind the rows of pass 0)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) next_ids[s][threadIdx.x] = idn[s];
+                for (int s = 0; s < NS; ++s) next_ids[s][threadIdx.x] = idn[s];
+            }
         }
         exchange(std::integral_constant<int, 3>{}, bv, bb, tp, tn);
         tp = it_flt(__builtin_amdgcn_readfirstlane(it_bits(tp)));
@@ -421,6 +632,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
             st_bounced++;
         }
         u = un; lo = lon; d = dn;
+        if constexpr (DMA) {
+            un = unn; lon = lonn; dn = dnn;
+            unn = u3; lonn = lo3; dnn = d3;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) idp[s] = idn[s];
+            idmp = idmn;
+        } else {
+            un = u3; lon = lo3; dn = d3;
+        }
     }
     if (stats && threadIdx.x == 0) {
         atomicAdd(stats + IT_STAT_DONE, st_done);
@@ -450,6 +670,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
 #ifndef IT_NS128S
 #define IT_NS128S 9
 #endif
+#ifndef IT_DMA
+#define IT_DMA 1             // ldv = 64 / 128 exactly: the next row prefetched into LDS by LDS-DMA (8 slots: 128 entries, two workgroups per CU)
+#endif
 #ifndef IT_OCC4
 #define IT_OCC4 3            // waves per SIMD of the four-wave geometries: ldv <= 128 without the split layout ...
 #endif
@@ -475,6 +698,7 @@ int wmf_iter_dmax(int f, int ld, int split) {
     // WMF_ITER_MIN_LDV = 0 sends them here as well.
     static const int min_ldv = (int)it_env("WMF_ITER_MIN_LDV", 65.f);
     if (ldv < min_ldv) return 0;
+    if (IT_DMA && (ldv == 64 || ldv == 128) && !it_env("WMF_ITER_NO_DMA", 0.f)) return 16 * 8;
     if (ldv <= 64) return 16 * (split ? IT_NS64S : IT_NS64);
     if (ldv <= 128) return 16 * (split ? IT_NS128S : IT_NS128);
     if (ldv <= 256) return 32 * 8;
@@ -482,12 +706,20 @@ int wmf_iter_dmax(int f, int ld, int split) {
     return 0;
 }
 
-template <int NW, int FPL, int NS, bool SPLIT, bool FULL, int OCC>
+template <int NW, int FPL, int NS, bool SPLIT, bool FULL, int OCC, bool DMA = false>
 static void it_launch(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* bounce_rows,
-                      int32_t* bounce_count, unsigned long long* stats, hipStream_t st) {
-    static const char* nm = wmf_kname("solve_iter_kernel<%d, %d, %d, %s, %s, %d>", NW, FPL, NS, SPLIT ? "true" : "false",
-                                      FULL ? "true" : "false", OCC);
+                      int32_t* bounce_count, unsigned long long* stats, const int4* info, hipStream_t st) {
+    static const char* nm = wmf_kname("solve_iter_kernel<%d, %d, %d, %s, %s, %d, %s>", NW, FPL, NS, SPLIT ? "true" : "false",
+                                      FULL ? "true" : "false", OCC, DMA ? "true" : "false");
+    using L = ItLds<NW, FPL>;
+    // (DMA variant: exchange buffers, the ring of the next row's gathered rows, its weights and border / bias values)
+    constexpr size_t dyn = DMA ? (size_t)L::EXCH * 4 + (size_t)NW * NS * (FPL / 4) * 1024 + NW * 768 : 0;
+    static bool attr_set = false;
+    if (DMA && !attr_set) {
+        (void)hipFuncSetAttribute((const void*)solve_iter_kernel<NW, FPL, NS, SPLIT, FULL, OCC, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        attr_set = true;
+    }
     // policy (environment overrides for experiments): start with the Neumann series while tau <= WMF_ITER_TAU (it converges
     // for tau < 1, at the rate of the row's LARGEST EIGENVALUE, usually far below tau) and move to the Chebyshev recurrence
     // when it contracts slower than that would; Chebyshev only while the bound on the condition number is <= WMF_ITER_KAPPA;
@@ -497,24 +729,34 @@ static void it_launch(const int32_t* rows, int64_t count, const float* V, const 
     static const float eps = it_env("WMF_ITER_EPS", 1.2e-7f);     // relative accuracy of a solved row: 2^-23, one float32 ulp
     const int64_t resident = 256LL * (OCC * 4 / NW);              // workgroups the chip holds
     const int64_t cap = resident * 4;                            // four rounds queued: rows differ in length
-    WMF_LAUNCH(nm, (solve_iter_kernel<NW, FPL, NS, SPLIT, FULL, OCC>), dim3((unsigned)(count < cap ? count : cap)), dim3(64 * NW), 0, st,
-               rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, tau_n, kap, kmax, eps * eps, stats);
+    WMF_LAUNCH(nm, (solve_iter_kernel<NW, FPL, NS, SPLIT, FULL, OCC, DMA>), dim3((unsigned)(count < cap ? count : cap)), dim3(64 * NW), dyn, st,
+               rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, tau_n, kap, kmax, eps * eps, stats, info);
 }
 
 // rows[0 .. count): candidates (more than 32 and at most wmf_iter_dmax entries).  side: NULL, or the {last feature, bias}
 // pairs of the split layout (V is then the packed body).  Rows that are not solved here are appended to bounce_rows.
 int wmf_launch_iter(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
                     const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* bounce_rows,
-                    int32_t* bounce_count, unsigned long long* stats, hipStream_t st) {
+                    int32_t* bounce_count, unsigned long long* stats, const void* info_v, hipStream_t st) {
+    const int4* info = static_cast<const int4*>(info_v);     // NULL, or {first entry lo, hi, row id, entries} of rows[i] (wmf_plan_create)
     if (count <= 0) return 0;
     const bool split = side != nullptr;
     const int ldv = it_ldv(f, ld, split);
 #define IT_GO(NW, FPL, NS, SP, OCC)                                                                                                      \
     do {                                                                                                                                 \
-        if (ldv == 16 * FPL) it_launch<NW, FPL, NS, SP, true, OCC>(rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, stats, st); \
-        else it_launch<NW, FPL, NS, SP, false, OCC>(rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, stats, st);            \
+        if (ldv == 16 * FPL) it_launch<NW, FPL, NS, SP, true, OCC>(rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, stats, info, st); \
+        else it_launch<NW, FPL, NS, SP, false, OCC>(rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, stats, info, st);            \
     } while (0)
     if (split && ldv > 128) return -1;                            // (the split layout exists for f <= 144 only)
+#if IT_DMA
+    if ((ldv == 64 || ldv == 128) && !it_env("WMF_ITER_NO_DMA", 0.f)) {
+#define IT_GO_DMA(FPL, SP) it_launch<4, FPL, 8, SP, true, 2, true>(rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, stats, info, st)
+        if (ldv == 64) { if (split) IT_GO_DMA(4, true); else IT_GO_DMA(4, false); }
+        else { if (split) IT_GO_DMA(8, true); else IT_GO_DMA(8, false); }
+#undef IT_GO_DMA
+        return 0;
+    }
+#endif
     if (ldv <= 64) { if (split) IT_GO(4, 4, IT_NS64S, true, IT_OCC4S); else IT_GO(4, 4, IT_NS64, false, IT_OCC64); }
     else if (ldv <= 128) { if (split) IT_GO(4, 8, IT_NS128S, true, IT_OCC4S); else IT_GO(4, 8, IT_NS128, false, IT_OCC4); }
     else if (ldv <= 192) IT_GO(8, 12, 8, false, 2);

@@ -699,7 +699,7 @@ static void launch_rowsplit_nfb(const wmf_plan* pl, const float* V, const float*
     const int64_t n_iter = biasv ? 0 : wmf_iter_rows(pl, f, ld, false);      // (biasv: always folded into vals by wmf_launch_solve)
     if (n_iter > 0)
         (void)wmf_launch_iter(rows, n_iter, V, nullptr, indptr, indices, vals, f, ld, g, pl->iter_bounce_rows, pl->fallback_count + 1,
-                              pl->iter_stats, st);
+                              pl->iter_stats, pl->iter_info, st);
     if (normal > n_iter) launch_rowsplit_f<NFB, BORDER, true, 0>(rows + n_iter, normal - n_iter, V, biasv, indptr, indices, vals, f, ld, g, pl, st);
     if (n_iter > 0) launch_rowsplit_f<NFB, BORDER, true, 0>(pl->iter_bounce_rows, n_iter, V, biasv, indptr, indices, vals, f, ld, g, pl, st, pl->fallback_count + 1);
     if (pl->heavy_count > 0) {          // rows with more than WMF_HEAVY_T entries: segments by separate workgroups, then one combine each

@@ -860,7 +860,7 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
             const int64_t all = pl->count[WMF_BIN_GENERAL];
             const int64_t n_iter = biasv ? 0 : wmf_iter_rows(pl, f, ld, false);
             if (n_iter > 0 && wmf_launch_iter(rows, n_iter, V, nullptr, indptr, indices, vals, f, ld, g, pl->iter_bounce_rows,
-                                              pl->fallback_count + 1, pl->iter_stats, st)) return -1;
+                                              pl->fallback_count + 1, pl->iter_stats, pl->iter_info, st)) return -1;
             if (all > n_iter && wmf_launch_wide(rows + n_iter, all - n_iter, V, biasv, indptr, indices, vals, f, ld, g,
                                                 pl->fallback_rows, pl->fallback_count, st)) return -1;
             if (n_iter > 0 && wmf_launch_wide(pl->iter_bounce_rows, n_iter, V, biasv, indptr, indices, vals, f, ld, g,
