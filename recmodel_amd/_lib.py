@@ -89,6 +89,11 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header and library out of sync
         fn.restype, fn.argtypes = res, args
+    # kernel-SELECTION switches for experiments (include/wmf_hip.h, wmf_debug_set_flags): every selection computes the same
+    # results; e.g. WMF_DEBUG_FLAGS=268435456 runs the whole parity suite without the matrix-free iteration kernel
+    flags = os.environ.get("WMF_DEBUG_FLAGS")
+    if flags:
+        lib.wmf_debug_set_flags(int(flags, 0))
     _lib = lib
     return lib
 

@@ -57,13 +57,19 @@ struct RsCfg {
     // LDS carve (floats)
     static constexpr int OFF_VS = 0;                              // [2][RC][LDV] staged factor rows, double buffered
     // F16A: instead the split operands of ONE 32-entry chunk: high parts [NFB][4][16] x 8 halves, then the low parts
-    static constexpr int OPS = NFB * 64 * 4;                      // floats per part (16 bytes per (block, q, r))
+    // Each part is SIXTEEN blocks whatever NFB is (round 4): every lane of a wave stages its piece -- lanes past the last
+    // tile column (4 NFB .. 63 at NFB < 16) write blocks nobody reads -- so that the staging has no divergent region
+    // (see stage32).  +3 KB per part at NFB = 13.
+    static constexpr int OPS = 16 * 64 * 4;                       // floats per part (16 bytes per (block, q, r))
     static constexpr int OFF_W = OFF_VS + (F16A ? 2 * OPS : 2 * RC * LDV);           // [2][RC] weights
     static constexpr int OFF_P = OFF_W + 2 * RC;                  // [2][RC] w + 1 (0 past the end of the row)
     static constexpr int OFF_PAN = OFF_P + 2 * RC;                 // [2][NFB][16][20]: {originals, W} of the pivot row, by block column
     // (F16A: the same two panels as split-f16 operands, [2][NFB][64 lanes] x 16 bytes; at least the 10 FP + 8 floats of the
     // right-hand-side scratch)
-    static constexpr int PAN = F16A ? (2 * NFB * 256 > 10 * FP + 8 ? 2 * NFB * 256 : 10 * FP + 8) : 2 * NFB * 320;
+    // (right-hand-side scratch: two planes [4 waves][256] for y and b -- a plane row is 64 lanes x 4 floats, written by every
+    // lane --, then y [FP], b [FP], the waves' c / e [8])
+    static constexpr int RHS = 2 * 4 * 256 + 2 * FP + 8;
+    static constexpr int PAN = F16A ? (2 * NFB * 256 > RHS ? 2 * NFB * 256 : RHS) : 2 * NFB * 320;
     static constexpr int OFF_WV = OFF_PAN + PAN;                  // [16] w_p of the pivot row (+ spare)
     static constexpr int OFF_G = OFF_WV + 32;                     // [FP] solution
     static constexpr int OFF_WB = OFF_G + FP;                     // BORDER: [FP] w^b_p of every pivot row, then [8] scalars
@@ -204,11 +210,11 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
                     l[j] = (_Float16)(sx - (float)hh);
                 }
             }
+            // (every lane stores: blocks NFB .. 15 of the padded planes are a dump -- no divergent region in the staging, so that
+            // nothing is spilled under one EXEC mask and reloaded under another)
             const int ft = 4 * lane + e;
-            if (lane < NPC) {
-                ops_hi[((ft >> 4) * 4 + W) * 16 + (ft & 15)] = h;
-                ops_lo[((ft >> 4) * 4 + W) * 16 + (ft & 15)] = l;
-            }
+            ops_hi[((ft >> 4) * 4 + W) * 16 + (ft & 15)] = h;
+            ops_lo[((ft >> 4) * 4 + W) * 16 + (ft & 15)] = l;
         }
     };
 
@@ -275,21 +281,19 @@ __device__ __forceinline__ void rs_body(float* __restrict__ sm, const int32_t* _
             }
             // right-hand side / border: four partial sums per feature (one per wave) -> y[16 bi + r] for the owner of row bi.
             // The scratch lives in the panel region, which the elimination only writes after the barriers below.
-            float* ysum = Pan;                                   // [4][FP]
-            float* bsum = Pan + 4 * C::FP;                       // [4][FP]
-            float* ys = Pan + 8 * C::FP;                         // [FP] y, [FP] b, [8] c / e per wave
-            if (lane < NPC) {
-                *reinterpret_cast<float4*>(&ysum[W * C::FP + 4 * lane]) = make_float4(yreg[0], yreg[1], yreg[2], yreg[3]);
-                if constexpr (BORDER) *reinterpret_cast<float4*>(&bsum[W * C::FP + 4 * lane]) = make_float4(breg[0], breg[1], breg[2], breg[3]);
-            }
+            float* ysum = Pan;                                   // [4][256]: every lane writes its four features (4 lane .. 4 lane + 3)
+            float* bsum = Pan + 4 * 256;                         // [4][256]
+            float* ys = Pan + 8 * 256;                           // [FP] y, [FP] b, [8] c / e per wave
+            *reinterpret_cast<float4*>(&ysum[W * 256 + 4 * lane]) = make_float4(yreg[0], yreg[1], yreg[2], yreg[3]);
+            if constexpr (BORDER) *reinterpret_cast<float4*>(&bsum[W * 256 + 4 * lane]) = make_float4(breg[0], breg[1], breg[2], breg[3]);
             if constexpr (BORDER) { if (lane == 0) { ys[2 * C::FP + 2 * W] = creg; ys[2 * C::FP + 2 * W + 1] = ereg; } }
             yreg[0] = yreg[1] = yreg[2] = yreg[3] = 0.f;
             breg[0] = breg[1] = breg[2] = breg[3] = 0.f;
             creg = ereg = 0.f;
             __syncthreads();
             if (tid < C::FP) {
-                ys[tid] = (ysum[tid] + ysum[C::FP + tid]) + (ysum[2 * C::FP + tid] + ysum[3 * C::FP + tid]);
-                if constexpr (BORDER) ys[C::FP + tid] = (bsum[tid] + bsum[C::FP + tid]) + (bsum[2 * C::FP + tid] + bsum[3 * C::FP + tid]);
+                ys[tid] = (ysum[tid] + ysum[256 + tid]) + (ysum[2 * 256 + tid] + ysum[3 * 256 + tid]);
+                if constexpr (BORDER) ys[C::FP + tid] = (bsum[tid] + bsum[256 + tid]) + (bsum[2 * 256 + tid] + bsum[3 * 256 + tid]);
             }
             __syncthreads();
             constexpr int NTALL = NFB * (NFB + 1) / 2;
@@ -643,28 +647,17 @@ static void launch_rowsplit_f(const int32_t* rows, int64_t count, const float* V
                               const int32_t* count_dev = nullptr) {
     using C = RsCfg<NFB, BORDER, F16A>;
     constexpr size_t lds = (size_t)C::TOTAL * 4;
-    // ROUND-3 FINDING, root cause NOT identified (tests/scale/fuzz_parity.py found it, the lab instrumentation is
-    // tools/lab/rowsplit_dump_instrumentation.patch).  The BORDER kernels with 13 .. 15 blocks (f = 209, 225, 241), built with
-    // hipcc's default flags, gave wrong and run-to-run different rows -- about 45 % of 1200 heavy rows -- whenever TWO of their
-    // workgroups shared a CU, and exact, reproducible ones when each had a CU to itself (grid <= 256, or more LDS than half
-    // a CU).  What was established on MI355X: only the right-hand side y goes wrong, already at the end of the accumulation
-    // (b, c and the tiles, summed by the same packed instructions from the same operands, stay exact); the amount of LDS, its
-    // layout, wait states in front of the asm blocks and vector instead of scalar loads change nothing; the same object
-    // code is right at one workgroup per CU; the file compiled with -fno-slp-vectorize (no v_pk_*_f32) is right at two; and so
-    // is the default build once an empty asm on yreg[e] keeps the vectoriser from pairing y with b in stage32's v_pk_fma_f32
-    // chain (lo half y, hi half b, the hi half of the multiplier pair written by a v_mul_f32 one or two instructions ahead).
-    // A stand-alone probe of that instruction pattern (tools/lab/pk_hazard_probe.hip, 2 and 8 waves per SIMD, low and high
-    // registers) does NOT fail, so the pattern alone is not the mechanism.  With the pairing left in (RS_Y_PAIRED, RS_KEEP_SLP=1)
-    // neither s_waitcnt 0 -- every counter -- at the start of stage32, of a row, or in front of the tile products (nothing is in flight
-    // that could land late), nor forming b.w eight instructions ahead of the chain changes it.
-    // Every other width 145 .. 257, with and without the border, is reproducible and exact either way (800-case sweep).
-    // Three independent guards, until the mechanism is known: that empty asm in stage32; the Makefile builds this file with
-    // -fno-slp-vectorize (measured neutral on cfg5s: 56.2 against 56.9 ms per iteration); and these three widths launch with at
-    // least 82 KB of LDS, so that a CU holds one of their workgroups.  RS_NO_ALONE (lab) removes the last one.
-#ifdef RS_NO_ALONE
-    constexpr bool ALONE = false;
-#else
+    // ROUND-3 FINDING, ROUND-4 RESOLUTION.  The BORDER kernels with 13 .. 15 blocks (f = 209, 225, 241) gave
+    // wrong and run-to-run different right-hand sides y whenever two of their workgroups shared a CU.  Those three are the only
+    // instantiations that combine a REAL divergent region in the staging (`lane < 4 NFB` with 4 NFB = 52 / 56 / 60 < 64; at
+    // NFB = 16 the test is always true) with heavy spilling (216 .. 376 bytes of scratch, ~400 SGPR spills).  Since round 4 the
+    // staging and the store of the y / b partial sums are branch-free -- every lane stores, into operand planes padded to sixteen
+    // blocks and into 256-float plane rows -- so every instantiation has the control flow of NFB = 16, which was always exact;
+    // the 82 KB LDS guard (one workgroup per CU, 1.5 .. 1.7 x slower at those widths) is gone.  RS_ALONE (lab) brings it back.
+#ifdef RS_ALONE
     constexpr bool ALONE = BORDER && NFB >= 13 && NFB <= 15;
+#else
+    constexpr bool ALONE = false;
 #endif
     constexpr size_t lds_launch = ALONE && lds < (size_t)82 * 1024 ? (size_t)82 * 1024 : lds;
     static bool attr_set = false;

@@ -813,8 +813,10 @@ def test_wide_rows_under_full_occupancy_are_right_and_reproducible(WMF, f, bias)
     """144 < f <= 257 with EVERY row heavy (30 .. 700 entries), more rows than the chip holds workgroups: all resident
     workgroups of the four-waves-per-row kernel are busy at once.  Round 3's fuzzing found the border widths with 13 .. 15 blocks
     (f = 209, 225, 241) wrong and different from run to run in exactly this situation -- two such workgroups on one CU -- while
-    the small ragged matrices of the other tests never filled a CU; wmf_rowsplit.hip now keeps those three to one workgroup per
-    CU.  Two runs must agree bit for bit, and 120 sampled rows must match the float64 oracle."""
+    the small ragged matrices of the other tests never filled a CU.  Round 4: the staging of wmf_rowsplit.hip is branch-free (the
+    divergent region `lane < 4 NFB` those three widths alone had is gone) and they run two workgroups per CU again; the same test
+    passes with every round-3 guard compiled out (tools/lab/r4_rs2.sh).  Two runs must agree bit for bit, and 120 sampled rows
+    must match the float64 oracle."""
     rng = np.random.default_rng(f)
     n, m_items = 1200, 700
     k = f - int(bias)
