@@ -462,6 +462,7 @@ int wmf_rank_topn(const float* users, const float* items, int f, int ld, int bia
     const int lrc = wmf_launch_rank(users, items, f, ld, bias, user_idx, cand_idx, n_cand, topn, out_pos, out_scores, workspace,
                                     workspace_bytes, (hipStream_t)stream);
     if (lrc == -3) { wmf_set_error("wmf_rank_topn: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)wmf_rank_ws_bytes(n_cand)); return WMF_EINVAL; }
+    if (lrc == -4) { wmf_set_error("wmf_rank_topn: too many keys for the device sort (2^32 or more)"); return WMF_EINVAL; }
     if (lrc) { wmf_set_error("wmf_rank_topn: device sort or copy failed"); return WMF_EHIP; }
     return check_launch("wmf_rank_topn");
 }
@@ -481,6 +482,7 @@ int wmf_rank_topn_batch(const float* users, const float* items, int f, int ld, i
     const int lrc = wmf_launch_rank_batch(users, items, f, ld, bias, user_idx, n_users, cand_idx, n_cand, topn, out_pos, out_scores,
                                           workspace, workspace_bytes, (hipStream_t)stream);
     if (lrc == -3) { wmf_set_error("wmf_rank_topn_batch: workspace too small"); return WMF_EINVAL; }
+    if (lrc == -4) { wmf_set_error("wmf_rank_topn_batch: too many keys for the device sort (2^32 or more)"); return WMF_EINVAL; }
     if (lrc) { wmf_set_error("wmf_rank_topn_batch: device sort failed"); return WMF_EHIP; }
     return check_launch("wmf_rank_topn_batch");
 }

@@ -80,7 +80,7 @@ int wmf_launch_coo_to_csr(const int64_t* rows, const int64_t* cols, const float*
     WMF_LAUNCH("csr_keys_kernel", csr_keys_kernel, dim3((unsigned)grid), dim3(256), 0, st, rows, cols, nnz, n_rows, n_cols, keys, ids,
                bad_flag);
     bool in_alt = false;
-    if (wmf_sort_u64(keys, skeys, ids, sids, nnz, bits, temp, st, &in_alt)) return -2;
+    if (const int src = wmf_sort_u64(keys, skeys, ids, sids, nnz, bits, temp, st, &in_alt)) return src;      // (-2 launch failure, -4 too many keys)
     if (!in_alt) { auto* tk = keys; keys = skeys; skeys = tk; auto* ti = ids; ids = sids; sids = ti; }   // (skeys / sids: the sorted arrays)
     WMF_LAUNCH("csr_gather_kernel", csr_gather_kernel, dim3((unsigned)grid), dim3(256), 0, st, skeys, sids, vals, nnz, n_cols, indices,
                values);

@@ -150,7 +150,7 @@ int wmf_launch_rank_batch(const float* users, const float* items, int f, int ld,
     int ubits = 1;
     while ((nu >> ubits) != 0) ++ubits;
     bool in_alt = false;
-    if (wmf_sort_u64(keys, skeys, pos, spos, nu * nc, 32 + ubits, temp, st, &in_alt)) return -2;
+    if (const int src = wmf_sort_u64(keys, skeys, pos, spos, nu * nc, 32 + ubits, temp, st, &in_alt)) return src;      // (-2 launch failure, -4 too many keys)
     hipLaunchKernelGGL(take_top_kernel, dim3(1024), dim3(256), 0, st, in_alt ? spos : pos, in_alt ? skeys : keys, nu, nc, topn, out_pos,
                        out_scores);
     return 0;
@@ -263,7 +263,7 @@ int wmf_launch_rank(const float* users, const float* items, int f, int ld, int b
     const size_t m = host_ctrl[1];
     if ((int64_t)m < topn || (int64_t)m > n) return -2;
     bool in_alt = false;
-    if (wmf_sort_u64(keys, skeys, nullptr, nullptr, (int64_t)m, 64, temp, st, &in_alt)) return -2;
+    if (const int src = wmf_sort_u64(keys, skeys, nullptr, nullptr, (int64_t)m, 64, temp, st, &in_alt)) return src;      // (-2 launch failure, -4 too many keys)
     if (!in_alt) skeys = keys;
     hipLaunchKernelGGL(rank_take_kernel, dim3((unsigned)((topn + 255) / 256 > 1024 ? 1024 : (topn + 255) / 256)), dim3(256), 0, st,
                        skeys, scores, topn, out_pos, out_scores);

@@ -150,7 +150,7 @@ int wmf_sort_u64(unsigned long long* keys, unsigned long long* keys_alt, uint32_
                  void* ws, hipStream_t st, bool* in_alt) {
     *in_alt = false;
     if (n <= 1 || bits <= 0) return 0;
-    if (n >= (1ll << 32)) return -1;                             // tile offsets and the payload are 32-bit (callers check first and say so)
+    if (n >= (1ll << 32)) return -4;                             // tile offsets and the payload are 32-bit (wmf_sort.h: "too many keys")
     const int64_t ntiles = (n + SORT_TILE - 1) / SORT_TILE, len = 16 * ntiles, nchunks = (len + SORT_SCAN_CHUNK - 1) / SORT_SCAN_CHUNK;
     uint32_t* hist = static_cast<uint32_t*>(ws);
     uint32_t* sums = hist + ((len + 63) / 64) * 64;

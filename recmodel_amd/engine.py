@@ -69,6 +69,18 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _HeldWork:
+    """An asynchronous collective together with the buffer it reads: whoever takes the work out of a pending list and waits
+    on it later still holds the buffer until that wait."""
+
+    def __init__(self, work, *buffers):
+        self.work, self.buffers = work, buffers
+
+    def wait(self):
+        self.work.wait()
+        self.buffers = ()
+
+
 class HipKernels:
     """The compute backend: every method is one entry point of libwmf_hip.so (include/wmf_hip.h) on
     torch-owned device buffers and torch's current HIP stream.  This is the only backend the package
@@ -422,7 +434,6 @@ class AlsEngine:
         self.chunk_range = {s: [(W * lo, W * (lo + ln)) for lo, ln in self.chunk_bounds[s]] for s in self.n}
         self.sparse = {s: False for s in self.n}
         self.need = {}
-        self._keep = []                                                        # send buffers of exchanges in flight
         dev, f32 = self.device, torch.float32
         z = lambda *shape, dtype=f32: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
         # local factor blocks [rows_per_rank, ld]; rows >= n_local are padding and stay zero
@@ -653,6 +664,7 @@ class AlsEngine:
         self.sparse[S] = True
         self.chunk_range[S] = [(int(coff[k]), int(coff[k + 1])) for k in range(C)]
         f32 = torch.float32
+        self._wait(S)                           # gathers of factors loaded before the interactions still write the old matrix
         self.X[S] = torch.zeros(n_compact, self.ld, dtype=f32, device=dev)
         self.V[S] = torch.zeros(n_compact, self.ldv, dtype=f32, device=dev)
         self.bias_vec[S] = torch.zeros(n_compact, 2, dtype=f32, device=dev) if self.split else torch.zeros(n_compact, dtype=f32, device=dev)
@@ -772,8 +784,7 @@ class AlsEngine:
         W = self.world
         if torch.distributed.get_backend(self.group) == "nccl":
             work = torch.distributed.all_to_all_single(out, send, list(recv_counts), list(send_counts), group=self.group, async_op=True)
-            self._keep.append(send)                  # the send buffer must outlive the call
-            return work
+            return _HeldWork(work, send)             # the send buffer lives exactly as long as its exchange is in flight
         cap = torch.tensor([send.shape[0]], dtype=torch.int64)
         torch.distributed.all_reduce(cap, op=torch.distributed.ReduceOp.MAX, group=self.group)
         pad = torch.zeros(int(cap.item()), send.shape[1], dtype=send.dtype, device=send.device)
@@ -807,8 +818,6 @@ class AlsEngine:
             if work is not None:
                 work.wait()
         self._pending[side] = []
-        if not any(self._pending.values()):
-            self._keep = []
 
     # ---------------------------------------------------------------- one half step
     def prepare(self, fixed):

@@ -25,12 +25,30 @@ def _csr_parts(mat):
             torch.from_numpy(mat.data.astype(np.float32)))
 
 
+# A float64 count matrix makes the reference solve every row system in float64 (NumPy's promotion at wmf_model.py:237-239).  The
+# float32 row kernels reproduce that to the stated tolerance (5e-4 per row; measured 1e-5) while the confidence weights are of
+# the benchmark's order; their error grows with the weights (cond(A_u) eps_f32: 1e-3 .. 6e-3 per row at weights of 1e6).  Above
+# this weight a float64 count matrix therefore takes the float64 device path -- the reference's own arithmetic -- and the
+# result is rounded to the model's dtype where the reference rounds it.
+F64_ROW_WEIGHT = 1024.0
+
+
+def _transformed_dtype(count_dtype, alpha, beta, pre_process_count):
+    """dtype of the confidence weights the reference ends up with (wmf_model.py:119-123), by NumPy's own rules."""
+    probe = np.ones(1, dtype=count_dtype)
+    with np.errstate(all="ignore"):
+        return (alpha * np.log(1 + beta * probe)).dtype if pre_process_count == 'log' else (alpha * probe).dtype
+
+
 class _Float64Steps:
     """The two half steps of an iteration in float64 on the device (wmf_half_step_f64: RecModel/wmf_model.py:242-309) for
     `train(cores > 1)` on a float64 count matrix.  Factors live here as dense float64 device tensors; after every iteration
     float32 copies go to the engine, whose evaluation kernels compute the MSE train() stops on."""
 
-    def __init__(self, model, eng, count_mat, alpha, beta, pre_process_count):
+    def __init__(self, model, eng, count_mat, alpha, beta, pre_process_count, store_float32=False):
+        # store_float32: the reference's cores = 1 variants solve a float64 count matrix's rows in float64 and STORE float32
+        # (wmf_model.py:217, :237-239) -- every half step's result is rounded to float32 before the next one reads it
+        self.store_float32 = bool(store_float32)
         self.eng, self.K, self.bias, self.gamma = eng, eng.K, bool(model.bias), float(model.gamma)
         dev = eng.device
         C = scipy.sparse.csr_matrix(count_mat)
@@ -51,7 +69,7 @@ class _Float64Steps:
         Y = self.X[fixed]
         out = torch.empty(n, self.f, dtype=torch.float64, device=Y.device)
         self.K.half_step_f64(Y, Y.shape[0], self.f, self.bias, indptr, indices, vals, n, self.gamma, out, self.ws, self.fail)
-        self.X[side] = out
+        self.X[side] = out.to(torch.float32).to(torch.float64) if self.store_float32 else out
 
     def iteration(self):
         self._half("users", "items")
@@ -64,7 +82,8 @@ class _Float64Steps:
             self.eng.set_factors(side, self.X[side].to(torch.float32))
 
     def factors(self):
-        return self.X["users"].cpu().numpy(), self.X["items"].cpu().numpy()
+        users, items = self.X["users"].cpu().numpy(), self.X["items"].cpu().numpy()
+        return (users.astype(np.float32), items.astype(np.float32)) if self.store_float32 else (users, items)
 
 
 class WMF(RecModel):
@@ -279,8 +298,13 @@ class WMF(RecModel):
     def _recompute(self, Y, C, lambda_reg, bias):
         _lib.require_gpu()
         lib = _lib.load()
-        Y = np.ascontiguousarray(Y, dtype=np.float32)
         C = scipy.sparse.csr_matrix(C)
+        if (np.result_type(np.asarray(Y).dtype, C.dtype) == np.float64 and C.nnz
+                and float(np.nanmax(np.abs(C.data))) > F64_ROW_WEIGHT):
+            # float64 row systems in the reference (:237-239), and weights beyond what the float32 kernels hold the tolerance
+            # for: the float64 device path, rounded to the model's dtype where the reference rounds (:217)
+            return self._recompute_par(np.asarray(Y, dtype=np.float64), C.astype(np.float64), lambda_reg, bias).astype(self.dtype)
+        Y = np.ascontiguousarray(Y, dtype=np.float32)
         indptr = np.ascontiguousarray(C.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(C.indices, dtype=np.int32)
         values = np.ascontiguousarray(C.data, dtype=np.float32)
@@ -365,10 +389,17 @@ class WMF(RecModel):
         # confidence transform of integer counts is float64 ('log', :120) or int64 ('linear', :123; the row products then
         # promote) -- so its training continues on float64 factors: the float64 device path then does the half steps, the
         # engine only the MSE (and builds neither float32 shards nor row plans).  float32 / float16 counts stay float32.
-        cdt = np.dtype(count_mat.dtype)
+        # Which arithmetic the reference's rows run in: NumPy's result type of the factors and the TRANSFORMED counts
+        # (np.log of int16 is float32, of int64 float64; alpha * int64 stays int64 and promotes with the float32 factors).
+        tdt = _transformed_dtype(count_mat.dtype, alpha, beta, pre_process_count)
+        rows64 = np.result_type(np.dtype(self.dtype), tdt) == np.float64
         f64 = None
-        if cores > 1 and (cdt.kind in 'iub' or cdt == np.float64):
+        if rows64 and (cores > 1 or np.dtype(self.dtype) == np.float64):
+            # (float64 factors: the Pool variants stack float64 rows, :242-265; a float64 model stores what it solves, :217)
             f64 = _Float64Steps(self, eng, count_mat, alpha, beta, pre_process_count)
+        elif rows64 and count_mat.nnz and self._max_weight(count_mat, alpha, beta, pre_process_count) > F64_ROW_WEIGHT:
+            # cores = 1: float64 rows, float32 factors (:217); the float32 kernels hold the tolerance up to F64_ROW_WEIGHT only
+            f64 = _Float64Steps(self, eng, count_mat, alpha, beta, pre_process_count, store_float32=True)
         else:
             indptr, indices, values = _csr_parts(count_mat)
             values = values.to(eng.device)
@@ -403,7 +434,7 @@ class WMF(RecModel):
             if count_improvement >= stopping_rounds:
                 break
         if f64 is not None:
-            self.users, self.items = f64.factors()          # float64, as the reference's Pool variants leave them
+            self.users, self.items = f64.factors()          # float64, as the reference's Pool variants leave them (float32 for cores = 1)
             self._freeze()
         else:
             self._pull(eng)
@@ -413,6 +444,14 @@ class WMF(RecModel):
             print(f"MSE Eval at iteration {iter}: {self._mse(eng, eval_shard)}")
             print(f"MSE Train at iteration {iter}: {self._mse(eng, train_shard)}")
         return iter
+
+    @staticmethod
+    def _max_weight(count_mat, alpha, beta, pre_process_count):
+        """Largest confidence weight in magnitude the transform (wmf_model.py:119-123) gives this count matrix."""
+        data = np.asarray(count_mat.data, dtype=np.float64)
+        with np.errstate(all="ignore"):
+            w = alpha * np.log(1 + beta * data) if pre_process_count == 'log' else alpha * data
+        return float(np.nanmax(np.abs(w))) if w.size else 0.0
 
     @staticmethod
     def _train_eval_shard(eng, eval_mat):

@@ -244,7 +244,38 @@ def make_train_par_int(WMF):
     print("train_par_int.npz", os.path.getsize(f"{OUT}/train_par_int.npz"))
 
 
+def make_train_dtypes(WMF):
+    """Which dtype the factors end in follows NumPy's promotion of the MODEL dtype and the TRANSFORMED counts (round 4):
+    int16 counts with cores = 2 stay float32 ('log': np.log of int16 is float32; 'linear': float32 * int16 is float32), a
+    float64 model dtype with float32 counts gives float64 rows (wmf_model.py:119-123, :237-239, :285-287)."""
+    base = make_counts(80, 40, 5, seed=71, dtype="float64")
+    util = base.copy()
+    util.data = np.minimum(util.data, 5.0)
+    out = {}
+    cases = {"int16_log": dict(cdt=np.int16, mode="log", mdt="float32", cores=2, alpha=10),
+             "int16_linear": dict(cdt=np.int16, mode="linear", mdt="float32", cores=2, alpha=2),
+             "f32_model64": dict(cdt=np.float32, mode="log", mdt="float64", cores=2, alpha=10),
+             "f32_model64_c1": dict(cdt=np.float32, mode="log", mdt="float64", cores=1, alpha=10)}
+    for name, c in cases.items():
+        counts = sp.csr_matrix((np.rint(base.data).astype(c["cdt"]), base.indices, base.indptr), shape=base.shape)
+        mdl = WMF(num_items=40, num_users=80, dim=5, gamma=0.1, weighted=True, bias=False, seed=1993, dtype=c["mdt"])
+        last = mdl.train(utility_mat=util, iterations=2, verbose=0, eval_mat=util, count_mat=counts, cores=c["cores"],
+                         stopping_rounds=5, pre_process_count=c["mode"], alpha=c["alpha"])
+        out[f"last_iter_{name}"] = last
+        out[f"users_{name}"] = mdl.users
+        out[f"items_{name}"] = mdl.items
+        out[f"mse_final_{name}"] = mdl.eval_prec(util)
+        print(name, mdl.users.dtype, mdl.items.dtype)
+    out.update(csr_fields("counts", base))
+    out.update(csr_fields("util", util))
+    np.savez_compressed(f"{OUT}/train_dtypes.npz", **out)
+    print("train_dtypes.npz", os.path.getsize(f"{OUT}/train_dtypes.npz"))
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["train_dtypes"]:                 # only the file added in round 4
+        make_train_dtypes(load_reference())
+        sys.exit(0)
     if sys.argv[1:] == ["train_par_int"]:                # only the file added in round 3
         make_train_par_int(load_reference())
         sys.exit(0)

@@ -399,6 +399,31 @@ def _weight_range_matrix(n, m_items, rng, mode):
     return sp.csr_matrix((w.astype(np.float32), indices, indptr), shape=(n, m_items)), np.array(degs)
 
 
+@pytest.mark.parametrize("k,bias,mode", [(64, False, "wide"), (128, True, "bias"), (256, False, "wide"), (256, True, "bias")])
+def test_weight_range_with_float64_counts_meets_the_tolerance(WMF, k, bias, mode):
+    """A float64 count matrix makes the reference solve its rows in float64 (wmf_model.py:237-239).  With weights up to 1e6 the
+    float32 kernels are 1e-3 .. 6e-3 off per row (round 3's measurement), so such a matrix takes the float64 device path
+    (recmodel_amd.wmf_model.F64_ROW_WEIGHT) and EVERY row meets the stated tolerance against the float64 oracle -- not
+    "5 x NumPy-float32"."""
+    rng = np.random.default_rng(1000 + k + bias)
+    n, m_items = 300, 6000
+    C, degs = _weight_range_matrix(n, m_items, rng, mode)
+    C64 = as_f64(C)
+    model = WMF(num_items=m_items, num_users=n, dim=k, gamma=0.1, weighted=True, bias=bias)
+    Y = model.items.copy()
+    if bias:
+        Y[:, 0] *= 0.5
+    want = (orc.recompute_factors_bias if bias else orc.recompute_factors)(Y, C64, 0.1, out_dtype="float64")
+    got = (model.recompute_factors_bias if bias else model.recompute_factors)(Y, C64, 0.1)
+    assert got.dtype == np.float32                                   # the reference stores the model's dtype (:217)
+    den = np.linalg.norm(want, axis=1)
+    ok = den > 0
+    e_got = np.linalg.norm(got.astype(np.float64) - want, axis=1)[ok] / den[ok]
+    record_error(f"weight_range_f64_counts[k={k},bias={int(bias)},{mode}]", worst_row=e_got.max(), median_row=float(np.median(e_got)))
+    assert e_got.max() <= (HALF_ROW if k + bias <= 144 else WIDE_ROW), e_got.max()
+    assert not got[degs == 0].any()
+
+
 @pytest.mark.parametrize("k,bias,mode", [(64, False, "wide"), (64, True, "bias"), (128, False, "wide"), (128, True, "bias"),
                                          (256, False, "wide"), (256, True, "bias"),
                                          (64, False, "overflow"), (128, False, "overflow"), (128, True, "overflow"), (256, False, "overflow")])
@@ -574,12 +599,36 @@ def test_train_cores2_integer_counts_vs_reference_golden(WMF):
                            pre_process_count=mode, alpha=(10 if mode == "log" else 2))
         assert last == int(g[f"last_iter_{mode}"])
         assert model.users.dtype == np.float64 and model.items.dtype == np.float64
+        # (2e-5, not 1e-8: the reference's first Gramian is a float32 product of the float32 initial items, ours is float64.  That
+        # gate alone would let a float32 solve cast to float64 through, so: the values must not be float32 numbers)
         assert fro(model.users, g[f"users_{mode}"]) <= 2e-5 and fro(model.items, g[f"items_{mode}"]) <= 2e-5
+        assert (model.users != model.users.astype(np.float32)).mean() > 0.9 and (model.items != model.items.astype(np.float32)).mean() > 0.9
         assert abs(model.eval_prec(util) - float(g[f"mse_final_{mode}"])) <= 1e-5 * float(g[f"mse_final_{mode}"])
     # cores = 1 on the same matrix: float32 factors (recompute_factors casts each row back, :217, :239)
     model = WMF(num_items=util.shape[1], num_users=util.shape[0], dim=6, gamma=0.1, weighted=True)
     model.train(utility_mat=util, iterations=1, eval_mat=util, count_mat=counts, cores=1, stopping_rounds=5)
     assert model.users.dtype == np.float32
+
+
+def test_train_dtype_follows_numpy_promotion_vs_reference_golden(WMF):
+    """Which dtype the factors end in is NumPy's promotion of the model dtype and the TRANSFORMED counts (golden
+    train_dtypes.npz from the reference itself, round 4): int16 counts with cores = 2 stay float32 (np.log of int16 is float32,
+    float32 * int16 is float32), a float64 model on float32 counts is float64 whatever `cores` is."""
+    g = load_golden("train_dtypes.npz")
+    base, util = csr_from(g, "counts"), csr_from(g, "util")
+    cases = {"int16_log": (np.int16, "log", "float32", 2, 10), "int16_linear": (np.int16, "linear", "float32", 2, 2),
+             "f32_model64": (np.float32, "log", "float64", 2, 10), "f32_model64_c1": (np.float32, "log", "float64", 1, 10)}
+    for name, (cdt, mode, mdt, cores, alpha) in cases.items():
+        counts = sp.csr_matrix((np.rint(base.data).astype(cdt), base.indices, base.indptr), shape=base.shape)
+        model = WMF(num_items=40, num_users=80, dim=5, gamma=0.1, weighted=True, bias=False, dtype=mdt)
+        last = model.train(utility_mat=util, iterations=2, eval_mat=util, count_mat=counts, cores=cores, stopping_rounds=5,
+                           pre_process_count=mode, alpha=alpha)
+        want_u, want_i = g[f"users_{name}"], g[f"items_{name}"]
+        assert last == int(g[f"last_iter_{name}"]), name
+        assert model.users.dtype == want_u.dtype and model.items.dtype == want_i.dtype, (name, model.users.dtype, want_u.dtype)
+        tol = 1e-8 if want_u.dtype == np.float64 else 2e-4
+        assert fro(model.users, want_u) <= tol and fro(model.items, want_i) <= tol, (name, fro(model.users, want_u), fro(model.items, want_i))
+        assert abs(model.eval_prec(util) - float(g[f"mse_final_{name}"])) <= 1e-4 * float(g[f"mse_final_{name}"]), name
 
 
 def test_train_argument_errors_like_reference(WMF):

@@ -179,3 +179,21 @@ def test_train_cores2_on_integer_counts_is_float64():
         np.testing.assert_allclose(users, g[f"users_{mode}"], rtol=RTOL, atol=ATOL)
         np.testing.assert_allclose(items, g[f"items_{mode}"], rtol=RTOL, atol=ATOL)
         assert abs(hist[-1] - float(g[f"mse_final_{mode}"])) <= 1e-6 * float(g[f"mse_final_{mode}"])
+
+
+def test_train_dtype_follows_numpy_promotion():
+    """Golden from the reference (make_golden.py train_dtypes, round 4): int16 counts with cores = 2 stay float32, a float64
+    model on float32 counts ends in float64 with cores = 1 and cores = 2."""
+    import scipy.sparse as sp
+    g = load_golden("train_dtypes.npz")
+    base, util = csr_from(g, "counts"), csr_from(g, "util")
+    cases = {"int16_log": (np.int16, "log", "float32", 2, 10), "int16_linear": (np.int16, "linear", "float32", 2, 2),
+             "f32_model64": (np.float32, "log", "float64", 2, 10), "f32_model64_c1": (np.float32, "log", "float64", 1, 10)}
+    for name, (cdt, mode, mdt, cores, alpha) in cases.items():
+        counts = sp.csr_matrix((np.rint(base.data).astype(cdt), base.indices, base.indptr), shape=base.shape)
+        last, hist, users, items = orc.train(40, 80, 5, 0.1, util, 2, util, count_mat=counts, weighted=True, bias=False,
+                                             stopping_rounds=5, cores=cores, pre_process_count=mode, alpha=alpha, dtype=mdt)
+        assert last == int(g[f"last_iter_{name}"]), name
+        assert users.dtype == g[f"users_{name}"].dtype and items.dtype == g[f"items_{name}"].dtype, (name, users.dtype)
+        np.testing.assert_allclose(users, g[f"users_{name}"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(items, g[f"items_{name}"], rtol=RTOL, atol=ATOL)
