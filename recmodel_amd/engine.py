@@ -73,11 +73,14 @@ class _HeldWork:
     """An asynchronous collective together with the buffer it reads: whoever takes the work out of a pending list and waits
     on it later still holds the buffer until that wait."""
 
-    def __init__(self, work, *buffers):
-        self.work, self.buffers = work, buffers
+    def __init__(self, work, *buffers, landing=None):
+        self.work, self.buffers, self.landing = work, buffers, landing     # landing: (device tensor, host tensor the exchange fills)
 
     def wait(self):
         self.work.wait()
+        if self.landing is not None:
+            self.landing[0].copy_(self.landing[1])
+            self.landing = None
         self.buffers = ()
 
 
@@ -778,31 +781,17 @@ class AlsEngine:
             self.X[side][W * lo: W * (lo + ln)], self.factors[side][lo: lo + ln], group=self.group, async_op=True))
 
     def _all_to_all_rows(self, out, send, recv_counts, send_counts):
-        """out = the rows every rank packed for this one (source-major), send = this rank's rows packed per destination.
-        RCCL: one asynchronous all_to_all_single with split sizes.  gloo (CPU rehearsal): every rank all-gathers the padded
-        send buffers and keeps its part.  Returns something with .wait() (or None)."""
-        W = self.world
-        if torch.distributed.get_backend(self.group) == "nccl":
+        """out = the rows every rank packed for this one (source-major), send = this rank's rows packed per destination:
+        ONE asynchronous all_to_all_single with split sizes, whatever the backend -- RCCL on device tensors; gloo (the CPU
+        rehearsal of the tests, and ranks sharing a GPU) on host tensors, device tensors staged through the host.  The same
+        split-size bookkeeping therefore runs under every test that 8 GPUs will run.  Returns something with .wait()."""
+        if torch.distributed.get_backend(self.group) == "nccl" or not out.is_cuda:
             work = torch.distributed.all_to_all_single(out, send, list(recv_counts), list(send_counts), group=self.group, async_op=True)
             return _HeldWork(work, send)             # the send buffer lives exactly as long as its exchange is in flight
-        cap = torch.tensor([send.shape[0]], dtype=torch.int64)
-        torch.distributed.all_reduce(cap, op=torch.distributed.ReduceOp.MAX, group=self.group)
-        pad = torch.zeros(int(cap.item()), send.shape[1], dtype=send.dtype, device=send.device)
-        pad[: send.shape[0]] = send
-        gathered = [torch.empty_like(pad) for _ in range(W)]
-        torch.distributed.all_gather(gathered, pad, group=self.group)
-        counts = torch.tensor(send_counts, dtype=torch.int64)
-        all_counts = [torch.empty_like(counts) for _ in range(W)]
-        torch.distributed.all_gather(all_counts, counts, group=self.group)
-        at = 0
-        for srcr in range(W):
-            cnts = all_counts[srcr]
-            lo = int(cnts[: self.rank].sum())
-            n = int(cnts[self.rank])
-            assert n == recv_counts[srcr]
-            out[at: at + n] = gathered[srcr][lo: lo + n]
-            at += n
-        return None
+        torch.cuda.current_stream().synchronize()    # (gloo reads the host copy: the rows must have been written)
+        send_h, out_h = send.cpu(), torch.empty(out.shape, dtype=out.dtype)
+        work = torch.distributed.all_to_all_single(out_h, send_h, list(recv_counts), list(send_counts), group=self.group, async_op=True)
+        return _HeldWork(work, send_h, landing=(out, out_h))
 
     def _ensure_gathered(self, side):
         """X[side] complete on this rank (reduce mode leaves it un-gathered until somebody needs it)."""

@@ -1,0 +1,143 @@
+"""The matrix-free iteration kernel (csrc/wmf_iter.hip, round 4) on every path it can take, at every geometry it has.
+
+A row with 33 .. wmf_iter_dmax entries is solved by a truncated polynomial in its operator E = V_u^T D V_u when tr E bounds it
+close enough to the identity: the Neumann series while tr E <= 0.8, the Chebyshev recurrence when the series contracts slowly
+or tr E is larger (condition bound <= 4), and it is HANDED BACK to the elimination kernels otherwise.  tr E ~ w d f / m, so
+the fixed side's size m and the weight scale steer the path: these tests build small matrices against a LARGE fixed side
+(whitened rows of norm^2 ~ f / m) and scale the weights, read the path shares back (wmf_plan_iter_stats) to make sure the
+path under test really ran, compare sampled rows with the float64 oracle (RecModel/wmf_model.py:231-239) at the gates of
+the elimination kernels, and demand bit-identical rows from two runs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import record_error
+from oracle import wmf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(n_rows, m_fixed, k, bias, deg_lo, deg_hi, scale, seed, neg_frac=0.0):
+    from recmodel_amd import WMF
+    from recmodel_amd.engine import AlsEngine
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(deg_lo, deg_hi + 1, n_rows)
+    indptr = np.concatenate([[0], np.cumsum(deg)])
+    indices = np.concatenate([np.sort(rng.choice(m_fixed, d, replace=False)) for d in deg]).astype(np.int64)
+    w = (scale * 10 * np.log(1 + rng.integers(1, 8, indptr[-1]))).astype(np.float32)
+    w[rng.random(w.size) < 0.02] = 0.0                              # stored zeros contribute p = 1 (wmf_model.py:232, :239)
+    eng = AlsEngine(n_rows, m_fixed, k, bias, 0.1)
+    eng.set_interactions(torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda(), torch.from_numpy(w).cuda())
+    Y = WMF(num_items=m_fixed, num_users=1, dim=k, gamma=0.1, weighted=True, bias=bias, seed=seed).items
+    if bias:                                                        # the fixed side's biases: small, or (neg_frac) large enough
+        Y[:, 0] *= 0.5                                              # to push a share of the weights below zero
+        if neg_frac:
+            Y[:, 0] = np.where(rng.random(m_fixed) < neg_frac, 25.0 * scale, Y[:, 0])
+    eng.set_factors("items", Y)
+    return eng, indptr, indices, w, Y
+
+
+def _check(eng, indptr, indices, w, Y, rows, gate_row, gate_fro, name):
+    f, bias = eng.f, eng.bias
+    Yd = Y.astype(np.float64)
+    Gy = Yd.copy()
+    if bias:
+        Gy[:, 0] = 1.0
+    G = Gy.T @ Gy + eng.gamma * np.eye(f)
+    got = eng.get_factors("users").astype(np.float64)
+    worst, num, den = 0.0, 0.0, 0.0
+    for u in rows:
+        lo, hi = indptr[u], indptr[u + 1]
+        idx, ww = indices[lo:hi], w[lo:hi].astype(np.float64)
+        U = Gy[idx]
+        if bias:
+            ww = ww - Yd[idx, 0]
+        want = orc.solve_row(G, U, np.arange(hi - lo), ww)
+        e, n_ = np.linalg.norm(got[u] - want), np.linalg.norm(want)
+        worst = max(worst, e / n_)
+        num += e * e
+        den += n_ * n_
+    fro = float(np.sqrt(num / den))
+    record_error(name, worst_row=worst, fro=fro)
+    assert worst <= gate_row and fro <= gate_fro, (name, worst, fro)
+
+
+# (k, bias): the kernel's geometries -- 4 waves x 8 features with and without the split layout's border (k = 128: the LDS-DMA
+# variant), pieces that end inside a row (k = 100), 8 waves x 12 / 16 / 20 features (k = 160, 256, 260)
+GEOMETRIES = [(128, True), (128, False), (100, False), (160, True), (256, False), (260, False)]
+
+
+@pytest.mark.parametrize("k,bias", GEOMETRIES)
+def test_iteration_paths_neumann_chebyshev_and_hand_back(k, bias):
+    m_fixed, n_rows = 400_000, 1500
+    f = k + int(bias)
+    dmax = 128 if k == 128 else (144 if k == 100 else (192 if k == 260 else 256))
+    tau1 = 15.0 * 60 * f / m_fixed                                 # tr E of a 60-entry row at scale 1, roughly
+    seen = set()
+    for label, scale in (("neumann", 0.01 / tau1), ("chebyshev", 1.5 / tau1), ("hand_back", 40.0 / tau1)):
+        # (the Neumann case covers every register slot of the geometry -- rows up to its longest --, the other two keep tr E in a
+        # band: rows of 33 .. 80 entries)
+        eng, indptr, indices, w, Y = _engine(n_rows, m_fixed, k, bias, 33, dmax if label == "neumann" else 80, scale, seed=100 + k)
+        eng.half_step("users")
+        eng.check_numerics()
+        eng.iter_stats("users")                                     # (clear: the counters below are those of ONE half step)
+        first = eng.get_factors("users").copy()
+        eng.half_step("users")
+        done, bounced, apps, cheb = (int(x) for x in eng.iter_stats("users"))
+        assert np.array_equal(first, eng.get_factors("users")), f"{label}: two runs differ"
+        assert done + bounced == n_rows, (label, done, bounced)
+        if label == "neumann":
+            assert bounced == 0 and cheb == 0 and apps <= 4 * done, (done, bounced, apps, cheb)
+        elif label == "chebyshev":
+            assert cheb > 0.5 * n_rows, (done, bounced, apps, cheb)
+        else:
+            assert bounced > 0.9 * n_rows, (done, bounced, apps, cheb)
+        seen.add(label)
+        rows = np.random.default_rng(k).choice(n_rows, 150, replace=False)
+        gate = (5e-5, 2e-5) if f <= 144 else (1e-4, 4e-5)
+        _check(eng, indptr, indices, w, Y, rows, *gate, name=f"iter_paths[k={k},bias={int(bias)},{label}]")
+        del eng
+        torch.cuda.empty_cache()
+    assert seen == {"neumann", "chebyshev", "hand_back"}
+
+
+def test_iteration_with_negative_weights():
+    """A bias model whose fixed-side biases push a share of the weights below zero: the row's operator is indefinite, the
+    spectrum bound becomes [1 - tau_minus, 1 + tau_plus]; rows stay on the iteration while tau_minus <= 1/2 and go back to the
+    elimination (and from there to the pivoted kernel) beyond."""
+    k, m_fixed, n_rows = 128, 400_000, 1200
+    for neg_frac, scale in ((0.05, 0.3), (0.5, 30.0)):
+        eng, indptr, indices, w, Y = _engine(n_rows, m_fixed, k, True, 40, 120, scale, seed=7, neg_frac=neg_frac)
+        eng.half_step("users")
+        eng.iter_stats("users")
+        eng.half_step("users")
+        eng.check_numerics()
+        done, bounced, apps, cheb = (int(x) for x in eng.iter_stats("users"))
+        if neg_frac < 0.1:
+            assert done > 0.9 * n_rows, (done, bounced)
+        else:
+            assert bounced > 0.9 * n_rows, (done, bounced)
+        rows = np.random.default_rng(3).choice(n_rows, 120, replace=False)
+        _check(eng, indptr, indices, w, Y, rows, 2e-3 if neg_frac > 0.1 else 5e-5, 5e-4 if neg_frac > 0.1 else 2e-5,
+               name=f"iter_negative_weights[{neg_frac}]")
+        del eng
+        torch.cuda.empty_cache()
+
+
+def test_iteration_off_gives_the_same_rows():
+    """Debug flag 268435456 sends every row to the elimination kernels: the two solvers must agree to float32 rounding on rows
+    the iteration solves (cfg3-like shape, scaled down)."""
+    from recmodel_amd import _lib
+    eng, indptr, indices, w, Y = _engine(4000, 300_000, 128, True, 33, 128, 0.5, seed=11)
+    eng.half_step("users")
+    a = eng.get_factors("users").copy()
+    lib = _lib.load()
+    try:
+        lib.wmf_debug_set_flags(268435456)
+        eng.half_step("users")
+    finally:
+        lib.wmf_debug_set_flags(0)
+    b = eng.get_factors("users")
+    rel = np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)
+    record_error("iter_vs_elimination", worst_row=float(rel.max()), median_row=float(np.median(rel)))
+    assert rel.max() <= 8e-6, rel.max()
