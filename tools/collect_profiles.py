@@ -14,7 +14,7 @@ src, prefix = sys.argv[1], sys.argv[2]
 bench_args = sys.argv[3] if len(sys.argv) > 3 else "--steps 5 --warmup 1"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
-OURS = re.compile(r"(gram\d*_|factorize|transform\d*_kernel<\d|solve_|eval_|predict_|confidence_|bias_adjust|spmm_|topk_|score_|csr_)")
+OURS = re.compile(r"(gram\d*_|factorize|transform\d*_kernel<\d|solve_|combine_segments|eval_|predict_|confidence_|bias_adjust|spmm_|topk_|score_|csr_)")
 
 
 def short(name):
@@ -43,6 +43,9 @@ with open(os.path.join(out, prefix + "_kernel_stats.csv"), "w", newline="") as f
 
 line = open(os.path.join(src, "bench_traced.json")).read().strip().splitlines()[-1]
 traced = json.loads(line)
+detail = os.path.join(src, "bench_detail_traced.json")       # round 4: the stdout line is compact, the kernel table is in the detail file
+if os.path.exists(detail):
+    traced = {**json.load(open(detail)), "stdout_line": traced}
 # kernels that ran in both half steps of an iteration (bench.py's table): their dispatches alternate users, items
 sides = {}
 for e in traced.get("kernels", []):

@@ -12,6 +12,7 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 cd $root
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline "$@" > $out/bench_traced.json 2> $out/trace.err || { tail -n 20 $out/trace.err; exit 1; }
+cp $root/gpurun_out/bench_detail.json $out/bench_detail_traced.json      # (the full record of that run: per-kernel table)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --no-cpu-baseline "$@" > /dev/null 2> $out/fetch.err || { tail -n 20 $out/fetch.err; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --no-cpu-baseline "$@" > /dev/null 2> $out/write.err || { tail -n 20 $out/write.err; exit 1; }
 python3 - "$out" <<'PY'
