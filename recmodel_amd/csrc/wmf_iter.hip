@@ -433,40 +433,58 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
         };
         // z = E y = V_u^T (D (V_u y)) over this wave's entries (partials: the caller's exchange sums them): pass A, t_e = w_e (v_e . y),
         // and pass B, z += t_e v_e, four slots at a time -- four independent chains, one 16-lane sum for the four
+        // (slots [S0, S0 + 4 NG) in ONE basic block: with two groups together the compiler has eight independent chains to
+        // interleave -- each wave spends a third of its time waiting to issue a dependent instruction, and only two waves
+        // share a SIMD)
+        auto apply_slots = [&]<int S0, int NG>(std::integral_constant<int, S0>, std::integral_constant<int, NG>, const it_f32x2 (&y)[H], float yb,
+                                               it_f32x2 (&z)[H], float& zb) {
+            constexpr int N = 4 * NG;
+            it_f32x2 a[N];
+            float tt[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) a[i] = (S0 + i < NS) ? vb[S0 + i < NS ? S0 + i : 0][0] * y[0] : it_f32x2{0.f, 0.f};
+#pragma unroll
+            for (int j = 1; j < H; ++j)
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    if (S0 + i < NS) a[i] = vb[S0 + i < NS ? S0 + i : 0][j] * y[j] + a[i];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                tt[i] = a[i][0] + a[i][1];
+                if constexpr (SPLIT) { if (S0 + i < NS) tt[i] = __builtin_fmaf(vbd[S0 + i < NS ? S0 + i : 0], yb, tt[i]); }
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < N; g4 += 4) wmf_row16_sum4(tt[g4], tt[g4 + 1], tt[g4 + 2], tt[g4 + 3]);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                if (S0 + i < NS) {
+                    const int s = S0 + i;
+                    const float t = tt[i] * wt[s];
+#pragma unroll
+                    for (int j = 0; j < H; ++j) z[j] = vb[s][j] * it_f32x2{t, t} + z[j];
+                    if constexpr (SPLIT) zb = __builtin_fmaf(t, vbd[s], zb);
+                }
+            }
+        };
+        constexpr bool PAIRS = NW == 4 && OCC == 2;            // (where registers allow: not at eight waves, not at three workgroups per CU)
         auto apply = [&](const it_f32x2 (&y)[H], float yb, it_f32x2 (&z)[H], float& zb) {
             zb = 0.f;
 #pragma unroll
             for (int j = 0; j < H; ++j) z[j] = it_f32x2{0.f, 0.f};
-#pragma unroll
-            for (int s4 = 0; s4 < NS; s4 += 4) {
-                if (s4 < ns) {
-                    it_f32x2 a[4];
-                    float tt[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) a[i] = (s4 + i < NS) ? vb[s4 + i < NS ? s4 + i : 0][0] * y[0] : it_f32x2{0.f, 0.f};
-#pragma unroll
-                    for (int j = 1; j < H; ++j)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (s4 + i < NS) a[i] = vb[s4 + i < NS ? s4 + i : 0][j] * y[j] + a[i];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        tt[i] = a[i][0] + a[i][1];
-                        if constexpr (SPLIT) { if (s4 + i < NS) tt[i] = __builtin_fmaf(vbd[s4 + i < NS ? s4 + i : 0], yb, tt[i]); }
-                    }
-                    wmf_row16_sum4(tt[0], tt[1], tt[2], tt[3]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (s4 + i < NS) {
-                            const int s = s4 + i;
-                            const float t = tt[i] * wt[s];
-#pragma unroll
-                            for (int j = 0; j < H; ++j) z[j] = vb[s][j] * it_f32x2{t, t} + z[j];
-                            if constexpr (SPLIT) zb = __builtin_fmaf(t, vbd[s], zb);
+            it_for<(NS + 7) / 8>([&](auto P) {
+                constexpr int s8 = 8 * IT_I(P);
+                if (s8 < ns) {
+                    if constexpr (PAIRS && s8 + 4 < NS) {
+                        if (s8 + 4 < ns) apply_slots(std::integral_constant<int, s8>{}, std::integral_constant<int, 2>{}, y, yb, z, zb);
+                        else apply_slots(std::integral_constant<int, s8>{}, std::integral_constant<int, 1>{}, y, yb, z, zb);
+                    } else {
+                        apply_slots(std::integral_constant<int, s8>{}, std::integral_constant<int, 1>{}, y, yb, z, zb);
+                        if constexpr (s8 + 4 < NS) {
+                            if (s8 + 4 < ns) apply_slots(std::integral_constant<int, s8 + 4>{}, std::integral_constant<int, 1>{}, y, yb, z, zb);
                         }
                     }
                 }
-            }
+            });
         };
 
         // ---- pass 0 (the first reader of what the gather requested: slot by slot as the rows land): the entry's weight and
