@@ -275,7 +275,7 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, int bias, wmf_plan*
     p->split = bias && wmf_split_layout(f, wmf_ld_for(f));
     if (e == hipSuccess && bias && !p->split && nnz_all > 0) e = hipMalloc((void**)&p->w_eff, (size_t)nnz_all * sizeof(float));
     if (e == hipSuccess && f > 144) e = hipMalloc((void**)&p->wide_ws, wmf_wide_lu_workspace_bytes(f));
-    if (e == hipSuccess && p->iter_count > 0) e = hipMalloc((void**)&p->iter_bounce_rows, (size_t)p->iter_count * sizeof(int32_t));
+    if (e == hipSuccess && p->iter_count > 0) e = hipMalloc((void**)&p->iter_bounce_rows, (size_t)2 * p->iter_count * sizeof(int32_t));   // [final list | stage 1's hand-on list]
     if (e == hipSuccess && p->iter_count > 0) {
         // the candidates' bookkeeping as one 16-byte record per row (the iteration kernel reads it with one scalar load)
         const int32_t* cand = order.data() + start[hb];
@@ -290,8 +290,8 @@ int wmf_plan_create(const int64_t* indptr, int64_t n, int f, int bias, wmf_plan*
         e = hipMalloc((void**)&p->iter_info, rec.size() * sizeof(int32_t));
         if (e == hipSuccess) e = hipMemcpy(p->iter_info, rec.data(), rec.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess && p->iter_count > 0) e = hipMalloc((void**)&p->iter_stats, 4 * sizeof(unsigned long long));
-    if (e == hipSuccess && p->iter_count > 0) e = hipMemset(p->iter_stats, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess && p->iter_count > 0) e = hipMalloc((void**)&p->iter_stats, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && p->iter_count > 0) e = hipMemset(p->iter_stats, 0, 8 * sizeof(unsigned long long));
     if (e == hipSuccess && p->heavy_count > 0) {
         const int64_t nfb = (f + 15) / 16, nt = nfb * (nfb + 1) / 2 + nfb;
         const int64_t pfloats = wmf_direct_supported(f) ? nt * 256 : wmf_rowsplit_partial_floats(f);
@@ -346,7 +346,7 @@ int wmf_plan_iter_stats(wmf_plan* p, int64_t* out4) {
     if (!p || !out4) { wmf_set_error("wmf_plan_iter_stats: null"); return WMF_EINVAL; }
     out4[0] = out4[1] = out4[2] = out4[3] = 0;
     if (!p->iter_stats) return WMF_OK;
-    unsigned long long h[4];
+    unsigned long long h[8];                                     // ([4]: rows the first stage handed to the second, not reported)
     hipError_t e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(h, p->iter_stats, sizeof(h), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemset(p->iter_stats, 0, sizeof(h));

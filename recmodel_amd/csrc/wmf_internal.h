@@ -38,9 +38,9 @@ struct wmf_plan {
     // matrix-free iteration kernel (wmf_iter.hip); fallback_count[1] counts the rows it hands back in iter_bounce_rows
     int64_t iter_count, iter_nnz;
     int iter_dmax;             // the candidates' longest admissible row at the width / layout the plan was created for
-    int32_t* iter_bounce_rows; // device: iter_count slots
+    int32_t* iter_bounce_rows; // device: 2 x iter_count slots (the rows handed back to the elimination kernels | stage 1's hand-on list)
     int32_t* iter_info;        // device: iter_count x {first entry (low, high word), row id, entries}: a candidate's bookkeeping in one 16-byte load
-    unsigned long long* iter_stats;   // device: 4 counters, accumulated over the launches (wmf_plan_iter_stats reads and clears)
+    unsigned long long* iter_stats;   // device: 8 counters (4 reported), accumulated over the launches (wmf_plan_iter_stats reads and clears)
 };
 
 int wmf_gram_max_waves(int f);

@@ -36,6 +36,7 @@
 
 typedef float it_f32x2 __attribute__((ext_vector_type(2)));
 
+
 __device__ __forceinline__ int it_bits(float v) { return __builtin_bit_cast(int, v); }
 __device__ __forceinline__ float it_flt(int v) { return __builtin_bit_cast(float, v); }
 
@@ -57,7 +58,7 @@ struct ItLds {
 };
 
 // counters of a launch (per plan, wmf_plan_iter_stats): rows solved here, rows bounced, applications of E in total
-enum { IT_STAT_DONE = 0, IT_STAT_BOUNCED = 1, IT_STAT_APPLICATIONS = 2, IT_STAT_CHEB = 3 };
+enum { IT_STAT_DONE = 0, IT_STAT_BOUNCED = 1, IT_STAT_APPLICATIONS = 2, IT_STAT_CHEB = 3, IT_STAT_STAGE1 = 4 };   // ([4]: rows stage 1 handed to stage 2)
 
 
 // ---- LDS access the compiler does not see (DMA variant): while an LDS-DMA (global_load_lds) may be outstanding hipcc puts
@@ -105,15 +106,21 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
                                                                  const float* __restrict__ vals, int f, int ld, float* __restrict__ g,
                                                                  int32_t* __restrict__ bounce_rows, int32_t* __restrict__ bounce_count,
                                                                  float tau_neumann, float kappa_max, int kmax, float eps2,
-                                                                 unsigned long long* __restrict__ stats, const int4* __restrict__ info) {
+                                                                 unsigned long long* __restrict__ stats, const int4* __restrict__ info,
+                                                                 const int32_t* __restrict__ count_dev, int bounce_stat) {
+    if (count_dev) count = *count_dev;                  // (stage 2: the rows stage 1 handed on; the count is on the device)
     constexpr int H = FPL / 2, P4 = FPL / 4, EPS = 4 * NW;
+    // The two-wave geometry (stage 1 at f = 128 / 129) runs the Neumann series only -- a fourth vector does not fit its
+    // registers; a row that needs the Chebyshev recurrence is handed to the four-wave kernel, which has it (wmf_launch_iter).
+    constexpr bool CHEB = NW != 2;
     using L = ItLds<NW, FPL>;
     static_assert(!DMA || (NW == 4 && FULL), "DMA variant: four waves, whole pieces");
     // DMA: [exchange buffers | ring: wave, slot, piece -> 1 KB (lane l at 16 l) | meta: wave -> weights, border, bias (64 dwords each)]
     constexpr int RING_OFF = L::EXCH * 4, META_OFF = RING_OFF + NW * NS * P4 * 1024;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     __shared__ __attribute__((aligned(16))) float lds_static[DMA ? 4 : L::EXCH];
-    __shared__ int next_ids[DMA ? 1 : NS][DMA ? 1 : 64 * NW];               // (no DMA) the next row's column ids wait here, not in registers
+    constexpr bool XL = false;                          // (lab: the solution in LDS during the Chebyshev recurrence; no geometry needs it)
+    __shared__ __attribute__((aligned(16))) float x_lds[XL ? 16 * FPL + 4 : 4];
     float* lds = DMA ? reinterpret_cast<float*>(dyn_lds) : lds_static;
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)dyn_lds);   // LDS byte address (DMA variant)
     const int lane = threadIdx.x & 63;
@@ -148,29 +155,50 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
             dd = (int)(indptr[uu + 1] - l);
         }
     };
-    auto fetch_ids = [&](int64_t l, int dd, int (&id)[NS]) {
+    // The column ids of a row travel as NID coalesced registers per wave -- lane l of register c holds the id of entry 64 c + l
+    // (every wave loads the whole row's ids: two to four 256-byte loads) -- and are fetched a row (DMA variant: two rows) ahead.
+    // A lane takes the ids of ITS entries (slot s: entry 4 NW s + 4 w + q) out of them with one ds_bpermute per slot: no
+    // per-slot id registers live across a row, no LDS parking (round-4 lab: sixteen id registers carried across the row were
+    // what spilled first, and a scratch store of a freshly loaded value waits for its load).
+    constexpr int NID = (EPS * NS + 63) / 64;
+    auto fetch_idc = [&](int64_t l, int dd, int (&ic)[NID]) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int e = EPS * s + 4 * wv + q;
-            id[s] = indices[l + (e < dd ? e : 0)];      // (unconditional: a select against a constant would make the register
-                                                        // write wait for every request in flight; entry 0 again is an L1 hit)
+        for (int c = 0; c < NID; ++c) {
+            const int e = 64 * c + lane;
+            ic[c] = indices[l + (e < dd ? e : 0)];      // (entries past the row's end: entry 0 again, an L1 hit; never used with weight)
 #ifdef IT_LAB_SAMEROWS                                  // lab: every row gathers the same few rows (cache hits): the kernel without its
-            id[s] &= 1023;                              // memory latency (results are those of a different matrix)
+            ic[c] &= 1023;                              // memory latency (results are those of a different matrix)
 #endif
         }
     };
-    // DMA variant: the requests of one row (l, dd) with the column ids id[] (slot layout) and idm (meta layout: lane l < 4 NS is
-    // entry 4 NW (l >> 2) + 4 w + (l & 3)): per slot in use P4 instructions of 64 x 16 bytes, then one dword instruction for the
-    // weights and two for the {border, bias} pairs.  Destinations are wave uniform (M0); a lane's data lands at 16 l / 4 l.
-    auto issue_dma = [&](int64_t l, int dd, const int (&id)[NS], int idm) {
+    auto slot_ids = [&](const int (&ic)[NID], int (&id)[NS]) {
+        it_for<NS>([&](auto S) {
+            constexpr int s = IT_I(S), c = (EPS * s) >> 6;      // (EPS divides 64: a slot's entries sit in one register)
+            id[s] = __builtin_amdgcn_ds_bpermute((((EPS * s) & 63) + 4 * wv + q) * 4, ic[c]);
+        });
+    };
+    auto meta_id = [&](const int (&ic)[NID]) {           // the id of this lane's entry in the meta layout (lane l < 4 NS: entry 4 NW (l >> 2) + 4 w + (l & 3))
+        const int e = (lane < 4 * NS) ? EPS * (lane >> 2) + 4 * wv + (lane & 3) : 0;
+        int v = __builtin_amdgcn_ds_bpermute((e & 63) * 4, ic[0]);
+#pragma unroll
+        for (int c = 1; c < NID; ++c) {
+            const int vc = __builtin_amdgcn_ds_bpermute((e & 63) * 4, ic[c]);
+            v = (e >> 6) == c ? vc : v;
+        }
+        return v;
+    };
+    // DMA variant: the requests of one row (l, dd) whose ids are ic: per slot in use P4 instructions of 64 x 16 bytes, then one
+    // dword instruction for the weights and two for the {border, bias} pairs.  Destinations are wave uniform (M0); a lane's data
+    // lands at 16 l / 4 l.  (Every id is formed before the first request: an id register produced between two requests would be
+    // waited for with vmcnt(0), i.e. behind the requests already issued.)
+    auto issue_dma = [&](int64_t l, int dd, const int (&ic)[NID]) {
         if constexpr (DMA) {
             const int nsn = (dd + EPS - 1) / EPS;
-            // every id is read here, once, before the first request: the compiler then waits for the id loads now -- left to
-            // itself it waits in front of each slot's address arithmetic, and as the requests of the slots before are younger
-            // than the id loads and conditional, that wait is vmcnt(0): each slot's fetch would complete before the next is issued
             int idl[NS];
+            slot_ids(ic, idl);
+            int idm = SPLIT ? meta_id(ic) : 0;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) { idl[s] = id[s]; asm volatile("" : "+v"(idl[s])); }
+            for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(idl[s]));
             asm volatile("" : "+v"(idm));
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -191,52 +219,35 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
             }
         }
     };
-    auto fetch_idm = [&](int64_t l, int dd) {           // the id of this lane's entry in the meta layout
-        const int e = EPS * (lane >> 2) + 4 * wv + (lane & 3);
-        int v = indices[l + ((lane < 4 * NS && e < dd) ? e : 0)];
-#ifdef IT_LAB_SAMEROWS
-        v &= 1023;
-#endif
-        return v;
-    };
-    // Pipeline of the bookkeeping (G = gridDim.x rows apart).  Without DMA: row i's trip requests the ids of row i + G and the
-    // record of row i + 2 G.  With DMA everything moves one row further ahead, so that the fetch of row i + G can be requested
-    // as soon as row i has been copied out of the ring, a whole row before it is needed: the trip of row i holds the ids of row
-    // i + G (idp / idmp, loaded during the trip before), requests those of row i + 2 G and the record of row i + 3 G.
+    // Pipeline of the bookkeeping (G = gridDim.x rows apart).  Without DMA: row i's trip holds its own ids (idc, loaded during
+    // the trip before), requests those of row i + G and the record of row i + 2 G.  With DMA everything moves one row further
+    // ahead, so that the fetch of row i + G can be requested as soon as row i has been copied out of the ring, a whole row
+    // before it is needed: the trip of row i holds the ids of row i + G, requests those of row i + 2 G and the record of row i + 3 G.
     const int64_t G = gridDim.x;
     int un = 0, dn = 0, unn = 0, dnn = 0;               // the records of the next two rows
     int64_t lon = 0, lonn = 0;
-    int idp[NS], idmp = 0;                              // DMA: ids of the next row, carried across the trip
+    int idc[NID];                                       // ids carried into the next trip (no DMA: of the trip's own row; DMA: of the row after)
+#pragma unroll
+    for (int c = 0; c < NID; ++c) idc[c] = 0;
     if (it + G < count) row_of(it + G, un, lon, dn);
     if (DMA && it + 2 * G < count) row_of(it + 2 * G, unn, lonn, dnn);
     if (it < count) {
         row_of(it, u, lo, d);
-        fetch_ids(lo, d, idx);
+        fetch_idc(lo, d, idc);
         if constexpr (DMA) {
-            issue_dma(lo, d, idx, SPLIT ? fetch_idm(lo, d) : 0);
-            if (it + G < count) {
-                fetch_ids(lon, dn, idp);
-                if constexpr (SPLIT) idmp = fetch_idm(lon, dn);
-            }
-        } else {
-            // (the first row's ids go through LDS like every later row's: one code path, and no request of the row loop ever
-            // waits on a load that was issued outside it)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) next_ids[s][threadIdx.x] = idx[s];
+            issue_dma(lo, d, idc);
+            if (it + G < count) fetch_idc(lon, dn, idc);
         }
     }
 
     for (; it < count; it += gridDim.x) {
         const int ns = (d + EPS - 1) / EPS;             // slots in use (wave uniform)
         const int ns4 = (ns + 3) & ~3;                  // ... rounded up to the groups of four the passes work in
-        if constexpr (!DMA) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) idx[s] = next_ids[s][threadIdx.x];
-        }
+        if constexpr (!DMA) slot_ids(idc, idx);
         // ---- gather: REQUESTS ONLY (nothing in this loop reads what it loads, so no wait separates the slots' requests):
         // body pieces, weight, border / bias pair of every entry of this wave
-        it_f32x2 vb[NS][H], pr[NS];
-        float vbd[NS], wt[NS];
+        it_f32x2 vb[NS][H];
+        float vbd[NS], wt[NS], bsv[NS];                     // bsv: the fixed side's bias of the entry, folded into the weight in pass 0
         // (first the zero entries that fill the last group of four -- a register write behind the requests would wait for them)
 #pragma unroll
         for (int s = 1; s < NS; ++s) {
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
 #pragma unroll
                 for (int j = 0; j < H; ++j) vb[s][j] = it_f32x2{0.f, 0.f};
                 wt[s] = 0.f;
-                pr[s] = it_f32x2{0.f, 0.f};
+                vbd[s] = 0.f; bsv[s] = 0.f;
             }
         }
         if constexpr (DMA) {
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
                         vb[s][2 * j + 1] = it_f32x2{piece[2], piece[3]};
                     });
                     wt[s] = it_ds_read32<16 * s>(meta_rd);
-                    if constexpr (SPLIT) pr[s] = it_f32x2{it_ds_read32<256 + 16 * s>(meta_rd), it_ds_read32<512 + 16 * s>(meta_rd)};
+                    if constexpr (SPLIT) { vbd[s] = it_ds_read32<256 + 16 * s>(meta_rd); bsv[s] = it_ds_read32<512 + 16 * s>(meta_rd); }
                 }
             });
             it_lgkm_wait();
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
 #pragma unroll
                 for (int j = 0; j < H; ++j) asm volatile("" : "+v"(vb[s][j])::"memory");
                 it_tie(wt[s]);
-                if constexpr (SPLIT) asm volatile("" : "+v"(pr[s])::"memory");
+                if constexpr (SPLIT) { it_tie(vbd[s]); it_tie(bsv[s]); }
             }
         } else {
 #pragma unroll
@@ -287,12 +298,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
                     vb[s][2 * j + 1] = it_f32x2{piece[2], piece[3]};
                 }
                 wt[s] = vals[lo + (e < d ? e : 0)];
-                if constexpr (SPLIT) pr[s] = *reinterpret_cast<const it_f32x2*>(side + 2 * (int64_t)idx[s]);
+                if constexpr (SPLIT) { vbd[s] = side[2 * (int64_t)idx[s]]; bsv[s] = side[2 * (int64_t)idx[s] + 1]; }   // {last feature, bias}
             }
         }
         }
         const int64_t itn = it + G;
-        int idn[NS], idmn = 0;
         int u3 = 0, d3 = 0;                                 // the record requested in this trip
         int64_t lo3 = 0;
         if constexpr (DMA) {
@@ -302,18 +312,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
             // id registers would still be in flight at the join -- where the first instruction to reuse one got an
             // s_waitcnt vmcnt(0), i.e. a wait for the whole prefetch right behind its issue.)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(idp[s]));
-            asm volatile("" : "+v"(idmp));
-            if (itn < count) issue_dma(lon, dn, idp, idmp);
+            for (int c = 0; c < NID; ++c) asm volatile("" : "+v"(idc[c]));
+            if (itn < count) issue_dma(lon, dn, idc);
             // ids of the row after the next, record of the one after that
-            if (itn + G < count) {
-                fetch_ids(lonn, dnn, idn);
-                if constexpr (SPLIT) idmn = fetch_idm(lonn, dnn);
-            }
+            if (itn + G < count) fetch_idc(lonn, dnn, idc);
             if (itn + 2 * G < count) row_of(itn + 2 * G, u3, lo3, d3);
         } else {
-            // the row after this one: ids requested now, parked in LDS behind pass 0, used at the next trip
-            if (itn < count) fetch_ids(lon, dn, idn);
+            // the row after this one: its ids requested now (they stay in idc until the next trip)
+            if (itn < count) fetch_idc(lon, dn, idc);
             if (itn + G < count) row_of(itn + G, u3, lo3, d3);
         }
 
@@ -441,6 +447,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
             constexpr int N = 4 * NG;
             it_f32x2 a[N];
             float tt[N];
+            const float ybm = yb * m0;                           // the border product enters the 16-lane sum once
 #pragma unroll
             for (int i = 0; i < N; ++i) a[i] = (S0 + i < NS) ? vb[S0 + i < NS ? S0 + i : 0][0] * y[0] : it_f32x2{0.f, 0.f};
 #pragma unroll
@@ -451,7 +458,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 tt[i] = a[i][0] + a[i][1];
-                if constexpr (SPLIT) { if (S0 + i < NS) tt[i] = __builtin_fmaf(vbd[S0 + i < NS ? S0 + i : 0], yb, tt[i]); }
+                if constexpr (SPLIT) { if (S0 + i < NS) tt[i] = __builtin_fmaf(vbd[S0 + i < NS ? S0 + i : 0], ybm, tt[i]); }
             }
 #pragma unroll
             for (int g4 = 0; g4 < N; g4 += 4) wmf_row16_sum4(tt[g4], tt[g4 + 1], tt[g4 + 2], tt[g4 + 3]);
@@ -498,10 +505,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
             if (s < ns) {
                 const bool valid = EPS * s + 4 * wv + q < d;
                 float w = wt[s];
-                if constexpr (SPLIT) {
-                    vbd[s] = pr[s][0] * m0;
-                    w -= pr[s][1];                       // the fixed side's bias comes with the row (RecModel/wmf_model.py:343)
-                }
+                if constexpr (SPLIT) w -= bsv[s];           // the fixed side's bias comes with the row (RecModel/wmf_model.py:343)
+                // (vbd: the same on the 16 lanes of a group -- its uses count it once, see ybm / m0)
                 w = valid ? w : 0.f;
                 wt[s] = w;
                 const float pp = valid ? w + 1.f : 0.f;  // p = w + 1 (wmf_model.py:239); nothing for the lanes past the row's end
@@ -520,22 +525,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
                 float nn = n2[0] + n2[1];
                 if constexpr (SPLIT) {
                     bb = __builtin_fmaf(pp, vbd[s], bb);
-                    nn = __builtin_fmaf(vbd[s], vbd[s], nn);
+                    nn = __builtin_fmaf(vbd[s] * m0, vbd[s], nn);   // (once per group: nn is summed over its 16 lanes)
                 }
                 tp = __builtin_fmaf(fmaxf(w, 0.f), nn, tp);
                 tn = __builtin_fmaf(fmaxf(-w, 0.f), nn, tn);
-            } else if (s < ns4) {
-                vbd[s] = 0.f;
             }
         }
         tp = wmf_row16_sum(tp);
         tn = wmf_row16_sum(tn);
-        if constexpr (!DMA) {
-            if (itn < count) {                              // (the ids have landed behind the rows of pass 0)
-#pragma unroll
-                for (int s = 0; s < NS; ++s) next_ids[s][threadIdx.x] = idn[s];
-            }
-        }
         exchange(std::integral_constant<int, 3>{}, bv, bb, tp, tn);
         tp = it_flt(__builtin_amdgcn_readfirstlane(it_bits(tp)));
         tn = it_flt(__builtin_amdgcn_readfirstlane(it_bits(tn)));
@@ -551,7 +548,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
         const float sigma = (sk - 1.f) * __builtin_amdgcn_rcpf(sk + 1.f);   // the Chebyshev iteration's asymptotic rate on that interval
         const float stop = eps2 * nb * alo * alo;
         bool converged = false, cheb = !(tau <= tau_neumann);
-        const bool go = cheb ? cheb_ok : true;
+        const bool go = cheb ? (CHEB && cheb_ok) : true;
         int napp = 0;
 
         it_f32x2 xv[H], rv[H];
@@ -578,6 +575,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
                 // contracting slowly (the row's operator has an eigenvalue near its bound tau): the Chebyshev recurrence on
                 // [alo, chi] does better from here, started from the present x with this term as its residual
                 if (cheb_ok && nr > fmaxf(sigma * sigma, 0.01f) * nprev) {
+                    if constexpr (!CHEB) break;                 // (handed on: converged stays false)
 #pragma unroll
                     for (int j = 0; j < H; ++j) rv[j] = z[j] * it_f32x2{sign, sign};
                     if constexpr (SPLIT) rb = sign * zb;
@@ -595,18 +593,44 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
             for (int j = 0; j < H; ++j) xv[j] = it_f32x2{0.f, 0.f};   // Chebyshev from x = 0, r = b
             xb = 0.f;
         }
-        if (go && cheb && !converged && cheb_ok) {
+        if (CHEB && go && cheb && !converged && cheb_ok) {
             // Chebyshev iteration for (I + E) x = b on [alo, chi] from (x, r): d_0 = r / theta, then
             //   x += d;  r -= (I + E) d;  rho' = 1 / (2 sigma_1 - rho);  d = rho' rho d + (2 rho' / delta) r        (sigma_1 = theta / delta)
+            // (two-wave geometry: x waits in LDS during this recurrence -- r, d and z are the registers the Neumann loop has for
+            // x, y and z, a fourth vector would spill; only the lanes that write the row out, wave 0 group 0, hold x at all)
             it_f32x2 dv[H];
             float db = rb * itheta, rho0 = delta * itheta;
             const float phi = delta * itheta;
+            const bool xowner = wv == 0 && q == 0;
+            auto x_add = [&](const it_f32x2 (&dx)[H], float dxb, float sc) {      // x += sc dx
+                if constexpr (XL) {
+                    if (xowner) {
+#pragma unroll
+                        for (int j = 0; j < P4; ++j) {
+                            f32x4 xo = *reinterpret_cast<f32x4*>(x_lds + r * FPL + 4 * j);
+                            xo += f32x4{dx[2 * j][0], dx[2 * j][1], dx[2 * j + 1][0], dx[2 * j + 1][1]} * sc;
+                            *reinterpret_cast<f32x4*>(x_lds + r * FPL + 4 * j) = xo;
+                        }
+                        if (SPLIT && r == 0) x_lds[16 * FPL] += sc * dxb;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < H; ++j) xv[j] = dx[j] * it_f32x2{sc, sc} + xv[j];
+                    if constexpr (SPLIT) xb = __builtin_fmaf(sc, dxb, xb);
+                }
+            };
+            if constexpr (XL) {
+                if (xowner) {
+#pragma unroll
+                    for (int j = 0; j < P4; ++j)
+                        *reinterpret_cast<f32x4*>(x_lds + r * FPL + 4 * j) = f32x4{xv[2 * j][0], xv[2 * j][1], xv[2 * j + 1][0], xv[2 * j + 1][1]};
+                    if (SPLIT && r == 0) x_lds[16 * FPL] = xb;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < H; ++j) dv[j] = rv[j] * it_f32x2{itheta, itheta};
             for (; napp < kmax;) {
-#pragma unroll
-                for (int j = 0; j < H; ++j) xv[j] += dv[j];
-                if constexpr (SPLIT) xb += db;
+                x_add(dv, db, 1.f);
                 it_f32x2 z[H];
                 float zb, z1 = 0.f, z2 = 0.f;
                 apply(dv, db, z, zb);
@@ -617,9 +641,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
                 if constexpr (SPLIT) rb = rb - db - zb;
                 const float nr = norm2(rv, rb);
                 if (nr * phi * phi <= stop) {           // one Richardson step more is free: its error is <= phi |A^-1 r|
-#pragma unroll
-                    for (int j = 0; j < H; ++j) xv[j] = rv[j] * it_f32x2{itheta, itheta} + xv[j];
-                    if constexpr (SPLIT) xb = __builtin_fmaf(rb, itheta, xb);
+                    x_add(rv, rb, itheta);
                     converged = true;
                     break;
                 }
@@ -630,6 +652,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
 #pragma unroll
                 for (int j = 0; j < H; ++j) dv[j] = rv[j] * it_f32x2{alpha, alpha} + dv[j] * it_f32x2{beta, beta};
                 if constexpr (SPLIT) db = alpha * rb + beta * db;
+            }
+            if constexpr (XL) {
+                if (xowner) {                                   // back into the registers the row is written from
+#pragma unroll
+                    for (int j = 0; j < P4; ++j) {
+                        const f32x4 xo = *reinterpret_cast<f32x4*>(x_lds + r * FPL + 4 * j);
+                        xv[2 * j] = it_f32x2{xo[0], xo[1]}; xv[2 * j + 1] = it_f32x2{xo[2], xo[3]};
+                    }
+                    if constexpr (SPLIT) xb = x_lds[16 * FPL];
+                }
             }
         }
         if (converged) {
@@ -653,16 +685,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
         if constexpr (DMA) {
             un = unn; lon = lonn; dn = dnn;
             unn = u3; lonn = lo3; dnn = d3;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) idp[s] = idn[s];
-            idmp = idmn;
         } else {
             un = u3; lon = lo3; dn = d3;
         }
     }
     if (stats && threadIdx.x == 0) {
         atomicAdd(stats + IT_STAT_DONE, st_done);
-        atomicAdd(stats + IT_STAT_BOUNCED, st_bounced);
+        atomicAdd(stats + bounce_stat, st_bounced);
         atomicAdd(stats + IT_STAT_APPLICATIONS, st_apps);
         atomicAdd(stats + IT_STAT_CHEB, st_cheb);
     }
@@ -691,6 +720,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
 #ifndef IT_DMA
 #define IT_DMA 1             // ldv = 64 / 128 exactly: the next row prefetched into LDS by LDS-DMA (8 slots: 128 entries, two workgroups per CU)
 #endif
+
+#ifndef IT_NW128
+#define IT_NW128 2           // ldv = 128 in two stages: two waves per row (16 slots of 8 entries, four workgroups per CU, plain loads,
+#endif                       // Neumann series only), then the four-wave DMA kernel over the rows that stage handed on.  4: the DMA kernel alone
 #ifndef IT_OCC4
 #define IT_OCC4 3            // waves per SIMD of the four-wave geometries: ldv <= 128 without the split layout ...
 #endif
@@ -716,6 +749,7 @@ int wmf_iter_dmax(int f, int ld, int split) {
     // WMF_ITER_MIN_LDV = 0 sends them here as well.
     static const int min_ldv = (int)it_env("WMF_ITER_MIN_LDV", 65.f);
     if (ldv < min_ldv) return 0;
+    if (IT_NW128 == 2 && ldv == 128) return 8 * 16;
     if (IT_DMA && (ldv == 64 || ldv == 128) && !it_env("WMF_ITER_NO_DMA", 0.f)) return 16 * 8;
     if (ldv <= 64) return 16 * (split ? IT_NS64S : IT_NS64);
     if (ldv <= 128) return 16 * (split ? IT_NS128S : IT_NS128);
@@ -727,7 +761,8 @@ int wmf_iter_dmax(int f, int ld, int split) {
 template <int NW, int FPL, int NS, bool SPLIT, bool FULL, int OCC, bool DMA = false>
 static void it_launch(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* bounce_rows,
-                      int32_t* bounce_count, unsigned long long* stats, const int4* info, hipStream_t st) {
+                      int32_t* bounce_count, unsigned long long* stats, const int4* info, hipStream_t st,
+                      const int32_t* count_dev = nullptr, int bounce_stat = IT_STAT_BOUNCED) {
     static const char* nm = wmf_kname("solve_iter_kernel<%d, %d, %d, %s, %s, %d, %s>", NW, FPL, NS, SPLIT ? "true" : "false",
                                       FULL ? "true" : "false", OCC, DMA ? "true" : "false");
     using L = ItLds<NW, FPL>;
@@ -746,9 +781,11 @@ static void it_launch(const int32_t* rows, int64_t count, const float* V, const 
     static const int kmax = (int)it_env("WMF_ITER_KMAX", 20.f);
     static const float eps = it_env("WMF_ITER_EPS", 1.2e-7f);     // relative accuracy of a solved row: 2^-23, one float32 ulp
     const int64_t resident = 256LL * (OCC * 4 / NW);              // workgroups the chip holds
-    const int64_t cap = resident * 4;                            // four rounds queued: rows differ in length
+    // four rounds queued (rows differ in length); over a device-side list -- usually empty -- one round: every workgroup of a
+    // launch has to be scheduled before it can find that out, 0.10 ms for 2048 workgroups of 72 KB of LDS
+    const int64_t cap = count_dev ? resident : resident * 4;
     WMF_LAUNCH(nm, (solve_iter_kernel<NW, FPL, NS, SPLIT, FULL, OCC, DMA>), dim3((unsigned)(count < cap ? count : cap)), dim3(64 * NW), dyn, st,
-               rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, tau_n, kap, kmax, eps * eps, stats, info);
+               rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, tau_n, kap, kmax, eps * eps, stats, info, count_dev, bounce_stat);
 }
 
 // rows[0 .. count): candidates (more than 32 and at most wmf_iter_dmax entries).  side: NULL, or the {last feature, bias}
@@ -766,6 +803,22 @@ int wmf_launch_iter(const int32_t* rows, int64_t count, const float* V, const fl
         else it_launch<NW, FPL, NS, SP, false, OCC>(rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, stats, info, st);            \
     } while (0)
     if (split && ldv > 128) return -1;                            // (the split layout exists for f <= 144 only)
+#if IT_NW128 == 2
+    if (ldv == 128 && !it_env("WMF_ITER_ONE_STAGE", 0.f)) {
+        // Stage 1: two waves per row -- half the per-row overhead of the four-wave form (exchanges, norms, vector updates are per
+        // wave) and four rows in flight per CU: 11.1 against 12.2 ms on the item side of BASELINE.json's configs[2] -- at the price of
+        // registers: no room for the Chebyshev recurrence's fourth vector.  What it does not solve (tau above the Neumann limit, a
+        // series that contracts slowly, no convergence) goes to the SECOND HALF of bounce_rows, counted in bounce_count[1].
+        // Stage 2: the four-wave LDS-DMA kernel over that list (count on the device; an empty list costs a few microseconds); what
+        // IT hands back is the final list, bounce_rows[0 ..) / bounce_count[0], for the elimination kernels.
+        int32_t* handed = bounce_rows + count;
+        if (split) it_launch<2, 8, 16, true, true, 2>(rows, count, V, side, indptr, indices, vals, f, ld, g, handed, bounce_count + 1, stats, info, st, nullptr, IT_STAT_STAGE1);
+        else it_launch<2, 8, 16, false, true, 2>(rows, count, V, side, indptr, indices, vals, f, ld, g, handed, bounce_count + 1, stats, info, st, nullptr, IT_STAT_STAGE1);
+        if (split) it_launch<4, 8, 8, true, true, 2, true>(handed, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, stats, nullptr, st, bounce_count + 1);
+        else it_launch<4, 8, 8, false, true, 2, true>(handed, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, stats, nullptr, st, bounce_count + 1);
+        return 0;
+    }
+#endif
 #if IT_DMA
     if ((ldv == 64 || ldv == 128) && !it_env("WMF_ITER_NO_DMA", 0.f)) {
 #define IT_GO_DMA(FPL, SP) it_launch<4, FPL, 8, SP, true, 2, true>(rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, stats, info, st)

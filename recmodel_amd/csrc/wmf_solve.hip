@@ -817,7 +817,7 @@ void wmf_launch_combine_segments(const wmf_plan* pl, int64_t partial_floats, hip
 int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, const int64_t* indptr,
                      const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* fail_count,
                      hipStream_t st) {
-    if (hipMemsetAsync(pl->fallback_count, 0, 2 * sizeof(int32_t), st) != hipSuccess) return -2;   // [0] pivoted fallback, [1] rows bounced by wmf_iter.hip
+    if (hipMemsetAsync(pl->fallback_count, 0, 3 * sizeof(int32_t), st) != hipSuccess) return -2;   // [0] pivoted fallback, [1] rows handed back by wmf_iter.hip, [2] its stage 1's hand-on list
     const int64_t nnz = pl->nnz[0] + pl->nnz[1] + pl->nnz[2] + pl->nnz[3];
     if (nnz == 0)                                                      // nothing stored: every row solves to zero
         return hipMemsetAsync(g, 0, (size_t)pl->n * ld * sizeof(float), st) == hipSuccess ? 0 : -2;
