@@ -556,7 +556,7 @@ def compact_line(full, detail_path):
         line["also"] = {}
         for name, r in full["also"].items():
             if "ms_per_step" not in r:                       # float64_path or an error record
-                line["also"][name] = {k: _r(v) for k, v in r.items() if k in ("ms_per_iteration", "vs_float32_path", "error", "cfg3_ms_per_iteration")}
+                line["also"][name] = {k: _r(v) for k, v in r.items() if k in ("ms_per_iteration", "vs_float32_path", "error", "cfg3_ms_per_iteration", "cfg3_vs_float32_path")}
                 continue
             ro = r.get("roofline") or {}
             line["also"][name] = {"ms_per_step": _r(r["ms_per_step"]), "value": _r(r["value"]), "kernel": ro.get("kernel"),
@@ -630,6 +630,12 @@ def main():
             f64_block = float64_path("cfg2", dev, lib)
             if also and "cfg2" in also:
                 f64_block["vs_float32_path"] = f64_block["ms_per_iteration"] / also["cfg2"]["ms_per_step"]
+            # ... and at the headline configuration's size (the faster of two timed iterations after one warm-up: 10 M x 129 float64 factors)
+            torch.cuda.empty_cache()
+            big = float64_path("cfg3", dev, lib, iters=2)
+            f64_block["cfg3_ms_per_iteration"] = big["ms_per_iteration"]
+            f64_block["cfg3_vs_float32_path"] = big["ms_per_iteration"] / main_res["ms_per_step"]
+            del big
         except Exception as exc:                      # reported, never silently dropped
             f64_block = {"error": repr(exc)}
     if also is not None and f64_block is not None:

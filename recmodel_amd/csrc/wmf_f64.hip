@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, TEAM == 64 ? F64_WAVE_TEAM_OCC : 1) void solve
                                                         const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                         const double* __restrict__ vals, int64_t n, double* __restrict__ X,
                                                         int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count, int team_doubles,
-                                                        const int32_t* __restrict__ ctrl) {
+                                                        const int32_t* __restrict__ ctrl, const int32_t* __restrict__ state) {
     extern __shared__ __attribute__((aligned(16))) double sm64[];
     constexpr int NTEAM = 256 / TEAM;
     const bool lowrank_on = ctrl[0] != 0;                            // rows with 1 .. F64_LR_D entries go through solve64lr_kernel then
@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256, TEAM == 64 ? F64_WAVE_TEAM_OCC : 1) void solve
             continue;
         }
         if (lowrank_on && hi - lo <= F64_LR_D) continue;
+        if (lowrank_on && state[row]) continue;                      // solved by the matrix-free iteration (wmf_iter64.hip)
         double acc[NB][16];
 #pragma unroll
         for (int n_ = 0; n_ < NB; ++n_)
@@ -412,8 +413,9 @@ __global__ void f64_count_low_kernel(const int64_t* __restrict__ indptr, int64_t
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&ctrl[1], c);
 }
 // ctrl[0] = 1: the low-rank path is on for this half step (enough rows for the whitening pass to pay, debug flag not set)
-__global__ void f64_decide_kernel(int32_t* __restrict__ ctrl, int64_t n, int off) {
-    ctrl[0] = (!off && (int64_t)ctrl[1] * 4 >= n && n > 0) ? 1 : 0;
+// (iter_on: the matrix-free iteration of wmf_iter64.hip reads the whitened factors for rows of every length)
+__global__ void f64_decide_kernel(int32_t* __restrict__ ctrl, int64_t n, int off, int iter_on) {
+    ctrl[0] = (!off && n > 0 && (iter_on || (int64_t)ctrl[1] * 4 >= n)) ? 1 : 0;
 }
 
 template <int NB>
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(64) void rinv64_kernel(const double* __restrict__ R
 template <int NB>
 __global__ __launch_bounds__(256) void transform64_kernel(const double* __restrict__ in, int64_t m, int f, const double* __restrict__ W,
                                                           int set_col0_one, double* __restrict__ out, const int64_t* __restrict__ indptr,
-                                                          const int32_t* __restrict__ ctrl, int64_t rows_per_block) {
+                                                          const int32_t* __restrict__ ctrl, int64_t rows_per_block, const int32_t* __restrict__ state) {
     extern __shared__ __attribute__((aligned(16))) double sm64[];
     if (ctrl[0] == 0) return;
     const int t = threadIdx.x;
@@ -541,7 +543,10 @@ __global__ __launch_bounds__(256) void transform64_kernel(const double* __restri
                 const int e = 4 * rb[n_] + x;
                 if (e >= nvalid) continue;
                 const int64_t row = c0 + e;
-                if (indptr) { const int64_t d = indptr[row + 1] - indptr[row]; if (d < 1 || d > F64_LR_D) continue; }
+                if (indptr) {                            // un-whitening: the low-rank rows and the rows the iteration solved
+                    const int64_t d = indptr[row + 1] - indptr[row];
+                    if ((d < 1 || d > F64_LR_D) && !(state && state[row])) continue;
+                }
 #pragma unroll
                 for (int y = 0; y < 4; ++y) { const int c = 4 * cb[n_] + y; if (c < f) out[row * f + c] = acc[4 * x + y]; }
             }
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(256) void solve64lr_kernel(const double* __restrict
                                                         const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                         const double* __restrict__ vals, int64_t n, double* __restrict__ gout,
                                                         int32_t* __restrict__ fb_rows, int32_t* __restrict__ fb_count,
-                                                        const int32_t* __restrict__ ctrl) {
+                                                        const int32_t* __restrict__ ctrl, const int32_t* __restrict__ state) {
     extern __shared__ __attribute__((aligned(16))) double sm64[];
     if (ctrl[0] == 0) return;
     constexpr int F4MAX = F64_LR_D / 4, LDY = F64_LR_D + 4;
@@ -580,6 +585,7 @@ __global__ __launch_bounds__(256) void solve64lr_kernel(const double* __restrict
         const int64_t lo = indptr[row], hi = indptr[row + 1];
         const int d = (int)min(hi - lo, (int64_t)(F64_LR_D + 1));
         if (d < 1 || d > F64_LR_D) continue;
+        if (state[row]) continue;                                    // solved by the matrix-free iteration (wmf_iter64.hip)
         // the system has f4 = ceil(d / 4) block rows (a 20-entry row: five block steps, not eight); its blocks are dealt to the lanes
         // for this row (the staged columns d .. 31, among them the right-hand-side block's, are zero)
         const int f4 = (d + 3) >> 2;
@@ -770,7 +776,7 @@ static int64_t f64_al(int64_t bytes) { return (bytes + 255) / 256 * 256; }
 int64_t wmf_f64_ws_bytes(int f, int64_t m, int64_t n) {
     const int64_t ff = (int64_t)f * f, f4 = (f + 3) / 4, FP = 4 * f4;
     return f64_al(8 * ((int64_t)gram64_blocks(m) * f64_blocks(f, false) * 16 + ff + (int64_t)WMF_F64_LU_GRID * (ff + f))) + f64_al(4 * (n + 64)) +
-           f64_al(8 * f4 * f4 * 16) + 2 * f64_al(8 * FP * FP) + f64_al(8 * m * f) + f64_al(8 * (n > 0 ? n : 1) * f) + 256;
+           f64_al(8 * f4 * f4 * 16) + 2 * f64_al(8 * FP * FP) + f64_al(8 * m * f) + f64_al(8 * (n > 0 ? n : 1) * f) + f64_al(4 * (n > 0 ? n : 1)) + 256;
 }
 
 template <int NB>
@@ -792,7 +798,8 @@ static void launch_gram64(const double* Y, int64_t m, int f, int bias, double la
 
 template <int NB, int TEAM, int R>
 static void launch_solve64(const double* Y, int f, int bias, const double* G, const int64_t* indptr, const int32_t* indices,
-                           const double* values, int64_t n, double* X, int32_t* fb_rows, int32_t* fb_count, const int32_t* ctrl, hipStream_t st) {
+                           const double* values, int64_t n, double* X, int32_t* fb_rows, int32_t* fb_count, const int32_t* ctrl, hipStream_t st,
+                           const int32_t* state) {
     const int team_doubles = (int)((solve64v2_team_doubles(f, R) + 1) & ~(size_t)1);           // 16-byte aligned slices
     const size_t lds = (size_t)team_doubles * 8 * (256 / TEAM);
     static bool attr_set = false;
@@ -805,7 +812,7 @@ static void launch_solve64(const double* Y, int f, int bias, const double* G, co
     int64_t grid = (n + teams - 1) / teams;
     if (grid > 4096) grid = 4096;
     WMF_LAUNCH(nms, (solve64v2_kernel<NB, TEAM, R>), dim3((unsigned)grid), dim3(256), lds, st, Y, f, bias, G, indptr, indices, values, n,
-               X, fb_rows, fb_count, team_doubles, ctrl);
+               X, fb_rows, fb_count, team_doubles, ctrl, state);
 }
 
 template <int NB>
@@ -817,7 +824,7 @@ static void launch_factor64(const double* G, int f, double* Rblk, int32_t* ctrl,
 
 template <int NB>
 static void launch_transform64(const double* in, int64_t m, int f, const double* W, int set_col0_one, double* out, const int64_t* indptr,
-                               const int32_t* ctrl, hipStream_t st) {
+                               const int32_t* ctrl, hipStream_t st, const int32_t* state = nullptr) {
     if (m <= 0) return;
     const int f4 = (f + 3) / 4, FP = 4 * f4;
     static bool attr_set = false;
@@ -830,7 +837,7 @@ static void launch_transform64(const double* in, int64_t m, int f, const double*
     const int64_t rpb = ((m + grid - 1) / grid + 15) / 16 * 16;
     static const char* nm = wmf_kname("transform64_kernel<%d>", NB);
     WMF_LAUNCH(nm, (transform64_kernel<NB>), dim3((unsigned)((m + rpb - 1) / rpb)), dim3(256), (size_t)16 * (FP + 1) * 8, st, in, m, f, W,
-               set_col0_one, out, indptr, ctrl, rpb);
+               set_col0_one, out, indptr, ctrl, rpb, state);
 }
 
 int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const int64_t* indptr, const int32_t* indices,
@@ -855,7 +862,13 @@ int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const 
     double* V = reinterpret_cast<double*>(base);
     base += f64_al(8 * m * f);
     double* gbuf = reinterpret_cast<double*>(base);
+    base += f64_al(8 * (n > 0 ? n : 1) * f);
+    int32_t* state = reinterpret_cast<int32_t*>(base);          // [n] 1: the row was solved by the matrix-free iteration (wmf_iter64.hip)
     if (hipMemsetAsync(fb_count, 0, 256, st) != hipSuccess) return -2;
+    if (n > 0 && hipMemsetAsync(state, 0, (size_t)n * 4, st) != hipSuccess) return -2;
+    // round 4: rows whose whitened system is close to the identity by a matrix-free Neumann series in float64 (wmf_iter64.hip)
+    // -- first: what it marks solved, the two kernels below skip; debug flags 134217728 (no whitened path) / 268435456 switch it off
+    const bool iter_on = wmf_iter_enabled() && wmf_iter64_dmax(f) > 0 && !(wmf_debug_flags & 134217728);
     switch (f64_nb(f64_blocks(f, false))) {
 #define C_(N) case N: launch_gram64<N>(Y, m, f, bias, lambda, partial, G, nwg, st); break;
         C_(1) C_(2) C_(3) C_(5) C_(9)
@@ -867,7 +880,7 @@ int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const 
         int64_t cgrid = (n + 255) / 256;
         if (cgrid > 1024) cgrid = 1024;
         hipLaunchKernelGGL(f64_count_low_kernel, dim3((unsigned)cgrid), dim3(256), 0, st, indptr, n, ctrl);
-        hipLaunchKernelGGL(f64_decide_kernel, dim3(1), dim3(1), 0, st, ctrl, n, (wmf_debug_flags & 134217728) ? 1 : 0);
+        hipLaunchKernelGGL(f64_decide_kernel, dim3(1), dim3(1), 0, st, ctrl, n, (wmf_debug_flags & 134217728) ? 1 : 0, iter_on ? 1 : 0);
         switch (f64_nb(f64_blocks(f, false))) {
 #define C_(N) case N: launch_factor64<N>(G, f, Rblk, ctrl, st); break;
             C_(1) C_(2) C_(3) C_(5) C_(9)
@@ -877,6 +890,10 @@ int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const 
         WMF_LAUNCH("rinv64_kernel", rinv64_kernel, dim3((unsigned)((FP + 63) / 64)), dim3(64), 0, st, Rblk, f, Rinv, RinvT, ctrl);
         if (4 * f4 <= 256) launch_transform64<1>(Y, m, f, Rinv, bias, V, nullptr, ctrl, st);
         else launch_transform64<2>(Y, m, f, Rinv, bias, V, nullptr, ctrl, st);
+        if (iter_on) {
+            if (wmf_launch_iter64(V, Y, f, bias, indptr, indices, values, n, 1, gbuf, state, ctrl, st)) return -1;
+            if (wmf_launch_iter64(V, Y, f, bias, indptr, indices, values, n, 0, gbuf, state, ctrl, st)) return -1;
+        }
         {
             static bool attr_set = false;
             if (!attr_set) {
@@ -886,13 +903,13 @@ int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const 
             int64_t grid = (n + 3) / 4;
             if (grid > 4096) grid = 4096;
             WMF_LAUNCH("solve64lr_kernel", solve64lr_kernel, dim3((unsigned)grid), dim3(256), (size_t)4 * F64_LR_TEAM_DOUBLES * 8, st, V, Y, f, bias,
-                       indptr, indices, values, n, gbuf, fb_rows, fb_count, ctrl);
+                       indptr, indices, values, n, gbuf, fb_rows, fb_count, ctrl, state);
         }
-        if (4 * f4 <= 256) launch_transform64<1>(gbuf, n, f, RinvT, 0, X, indptr, ctrl, st);
-        else launch_transform64<2>(gbuf, n, f, RinvT, 0, X, indptr, ctrl, st);
+        if (4 * f4 <= 256) launch_transform64<1>(gbuf, n, f, RinvT, 0, X, indptr, ctrl, st, state);
+        else launch_transform64<2>(gbuf, n, f, RinvT, 0, X, indptr, ctrl, st, state);
         // ---- every other row (all of them when the low-rank path is off): the f x f system directly
         const int nblk = f64_blocks(f, true);
-#define S_(N, T, R) launch_solve64<N, T, R>(Y, f, bias, G, indptr, indices, values, n, X, fb_rows, fb_count, ctrl, st)
+#define S_(N, T, R) launch_solve64<N, T, R>(Y, f, bias, G, indptr, indices, values, n, X, fb_rows, fb_count, ctrl, st, state)
         const bool waves = !(wmf_debug_flags & 67108864);       // debug flag 67108864 (timing experiments): workgroup teams at every width
         if (!waves && nblk <= 256) S_(1, 256, 16);
         else if (nblk <= 64) S_(1, 64, 8);            // one WAVE per row while a lane holds at most three blocks (f <= 68)

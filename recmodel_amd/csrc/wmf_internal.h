@@ -142,6 +142,10 @@ int64_t wmf_f64_ws_bytes(int f, int64_t m, int64_t n);
 int wmf_launch_half_step_f64(const double* Y, int64_t m, int f, int bias, const int64_t* indptr, const int32_t* indices,
                              const double* values, int64_t n, double lambda, double* X, void* ws, int32_t* fail, hipStream_t st);
 int wmf_launch_confidence_f64(double* values, int64_t nnz, double alpha, double beta, int mode, hipStream_t st);
+// wmf_iter64.hip: the matrix-free iteration in float64 (rows of 1 .. 32 entries: low = 1; 33 .. wmf_iter64_dmax: low = 0)
+int wmf_iter64_dmax(int f);
+int wmf_launch_iter64(const double* V, const double* Y, int f, int bias, const int64_t* indptr, const int32_t* indices,
+                      const double* vals, int64_t n, int low, double* gout, int32_t* state, const int32_t* ctrl, hipStream_t st);
 
 void wmf_set_error(const char* fmt, ...);
 // Ablation switches whose results are WRONG (1 no elimination, 2 no accumulation MFMAs, 8 no tile inverse) are compiled

@@ -140,3 +140,58 @@ def test_iteration_off_gives_the_same_rows():
     rel = np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)
     record_error("iter_vs_elimination", worst_row=float(rel.max()), median_row=float(np.median(rel)))
     assert rel.max() <= 4.2e-6, rel.max()                         # measured 1.4e-6
+
+
+@pytest.mark.parametrize("k,bias", [(64, False), (64, True), (100, False), (128, True)])
+def test_float64_iteration_against_the_float64_oracle(k, bias):
+    """The float64 form of the iteration (csrc/wmf_iter64.hip, inside wmf_half_step_f64 -- the reference's cores > 1 variants,
+    wmf_model.py:242-309): rows of 1 .. 32 entries (one wave per row) and of 33 .. 256 / 192 / 144 entries (four waves)
+    against a LARGE fixed side, so that tr E is small and the series runs; 1e-10 of oracle.solve_row like every float64 test, and
+    the same rows with the iteration switched off (debug flag 268435456: blocked Cholesky / low-rank kernels) agree to 1e-12."""
+    from recmodel_amd import _lib
+    from recmodel_amd.engine import HipKernels
+    f = k + int(bias)
+    rng = np.random.default_rng(500 + f)
+    m_fixed, n_rows = 300_000, 1200
+    dmax = {64: 256, 65: 192, 100: 144, 129: 144}[f]
+    deg = np.concatenate([rng.integers(1, 33, n_rows // 2), rng.integers(33, dmax + 1, n_rows - n_rows // 2)])
+    indptr = np.concatenate([[0], np.cumsum(deg)])
+    indices = np.concatenate([np.sort(rng.choice(m_fixed, d, replace=False)) for d in deg]).astype(np.int32)
+    w = 10 * np.log(1 + rng.integers(1, 8, indptr[-1])).astype(np.float64)
+    w[rng.random(w.size) < 0.02] = 0.0
+    Y = rng.random((m_fixed, f))
+    if bias:
+        Y[:, 0] *= 0.5
+    K = HipKernels()
+    dev = torch.device("cuda:0")
+    Yd = torch.from_numpy(Y).to(dev)
+    ip, ix, wd = torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev), torch.from_numpy(w).to(dev)
+    ws = torch.empty(K.half_step_f64_workspace_bytes(f, m_fixed, n_rows), dtype=torch.uint8, device=dev)
+    fail = torch.zeros(4, dtype=torch.int32, device=dev)
+    outs = []
+    lib = _lib.load()
+    for flags in (0, 268435456):
+        out = torch.empty(n_rows, f, dtype=torch.float64, device=dev)
+        try:
+            lib.wmf_debug_set_flags(flags)
+            K.half_step_f64(Yd, m_fixed, f, bias, ip, ix, wd, n_rows, 0.1, out, ws, fail)
+            torch.cuda.synchronize()
+        finally:
+            lib.wmf_debug_set_flags(0)
+        assert int(fail[0]) == 0
+        outs.append(out.cpu().numpy())
+    Gy = Y.copy()
+    if bias:
+        Gy[:, 0] = 1.0
+    G = Gy.T @ Gy + 0.1 * np.eye(f)
+    worst = 0.0
+    for u in rng.choice(n_rows, 160, replace=False):
+        lo, hi = indptr[u], indptr[u + 1]
+        idx, ww = indices[lo:hi], w[lo:hi].copy()
+        if bias:
+            ww = ww - Y[idx, 0]
+        want = orc.solve_row(G, Gy[idx], np.arange(hi - lo), ww)
+        worst = max(worst, np.linalg.norm(outs[0][u] - want) / np.linalg.norm(want))
+    both = np.linalg.norm(outs[0] - outs[1], axis=1) / np.linalg.norm(outs[1], axis=1)
+    record_error(f"iter64[k={k},bias={int(bias)}]", worst_row=float(worst), vs_direct_kernels=float(both.max()))
+    assert worst <= 1e-10 and both.max() <= 1e-12, (worst, both.max())
