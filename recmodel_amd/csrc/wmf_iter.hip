@@ -442,12 +442,26 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
         // (slots [S0, S0 + 4 NG) in ONE basic block: with two groups together the compiler has eight independent chains to
         // interleave -- each wave spends a third of its time waiting to issue a dependent instruction, and only two waves
         // share a SIMD)
-        auto apply_slots = [&]<int S0, int NG>(std::integral_constant<int, S0>, std::integral_constant<int, NG>, const it_f32x2 (&y)[H], float yb,
-                                               it_f32x2 (&z)[H], float& zb) {
+        // TAIL: the row's last group -- the slots past the row's end (one to three of them; they hold zeros) are skipped, not computed
+        auto apply_slots = [&]<int S0, int NG, bool TAIL>(std::integral_constant<int, S0>, std::integral_constant<int, NG>, std::bool_constant<TAIL>,
+                                                          const it_f32x2 (&y)[H], float yb, it_f32x2 (&z)[H], float& zb) {
             constexpr int N = 4 * NG;
             it_f32x2 a[N];
             float tt[N];
             const float ybm = yb * m0;                           // the border product enters the 16-lane sum once
+            if constexpr (TAIL) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    tt[i] = 0.f;
+                    if (S0 + i < NS && S0 + i < ns) {
+                        a[i] = vb[S0 + i < NS ? S0 + i : 0][0] * y[0];
+#pragma unroll
+                        for (int j = 1; j < H; ++j) a[i] = vb[S0 + i < NS ? S0 + i : 0][j] * y[j] + a[i];
+                        tt[i] = a[i][0] + a[i][1];
+                        if constexpr (SPLIT) tt[i] = __builtin_fmaf(vbd[S0 + i < NS ? S0 + i : 0], ybm, tt[i]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < N; ++i) a[i] = (S0 + i < NS) ? vb[S0 + i < NS ? S0 + i : 0][0] * y[0] : it_f32x2{0.f, 0.f};
 #pragma unroll
@@ -460,11 +474,12 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
                 tt[i] = a[i][0] + a[i][1];
                 if constexpr (SPLIT) { if (S0 + i < NS) tt[i] = __builtin_fmaf(vbd[S0 + i < NS ? S0 + i : 0], ybm, tt[i]); }
             }
+            }
 #pragma unroll
             for (int g4 = 0; g4 < N; g4 += 4) wmf_row16_sum4(tt[g4], tt[g4 + 1], tt[g4 + 2], tt[g4 + 3]);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                if (S0 + i < NS) {
+                if (S0 + i < NS && (!TAIL || S0 + i < ns)) {
                     const int s = S0 + i;
                     const float t = tt[i] * wt[s];
 #pragma unroll
@@ -480,14 +495,24 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
             for (int j = 0; j < H; ++j) z[j] = it_f32x2{0.f, 0.f};
             it_for<(NS + 7) / 8>([&](auto P) {
                 constexpr int s8 = 8 * IT_I(P);
+                constexpr auto one = std::integral_constant<int, 1>{};
+                constexpr auto two = std::integral_constant<int, 2>{};
+                auto group = [&](auto S) {                          // one group of four, whole or the row's last
+                    constexpr int s4 = IT_I(S);
+                    if (s4 + 4 <= ns) apply_slots(S, one, std::false_type{}, y, yb, z, zb);
+                    else apply_slots(S, one, std::true_type{}, y, yb, z, zb);
+                };
                 if (s8 < ns) {
                     if constexpr (PAIRS && s8 + 4 < NS) {
-                        if (s8 + 4 < ns) apply_slots(std::integral_constant<int, s8>{}, std::integral_constant<int, 2>{}, y, yb, z, zb);
-                        else apply_slots(std::integral_constant<int, s8>{}, std::integral_constant<int, 1>{}, y, yb, z, zb);
+                        if (s8 + 8 <= ns) apply_slots(std::integral_constant<int, s8>{}, two, std::false_type{}, y, yb, z, zb);
+                        else {
+                            group(std::integral_constant<int, s8>{});
+                            if (s8 + 4 < ns) group(std::integral_constant<int, s8 + 4>{});
+                        }
                     } else {
-                        apply_slots(std::integral_constant<int, s8>{}, std::integral_constant<int, 1>{}, y, yb, z, zb);
+                        group(std::integral_constant<int, s8>{});
                         if constexpr (s8 + 4 < NS) {
-                            if (s8 + 4 < ns) apply_slots(std::integral_constant<int, s8 + 4>{}, std::integral_constant<int, 1>{}, y, yb, z, zb);
+                            if (s8 + 4 < ns) group(std::integral_constant<int, s8 + 4>{});
                         }
                     }
                 }
