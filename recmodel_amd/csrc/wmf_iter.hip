@@ -119,8 +119,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
     constexpr int RING_OFF = L::EXCH * 4, META_OFF = RING_OFF + NW * NS * P4 * 1024;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     __shared__ __attribute__((aligned(16))) float lds_static[DMA ? 4 : L::EXCH];
-    constexpr bool XL = false;                          // (lab: the solution in LDS during the Chebyshev recurrence; no geometry needs it)
-    __shared__ __attribute__((aligned(16))) float x_lds[XL ? 16 * FPL + 4 : 4];
     float* lds = DMA ? reinterpret_cast<float*>(dyn_lds) : lds_static;
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)dyn_lds);   // LDS byte address (DMA variant)
     const int lane = threadIdx.x & 63;
@@ -621,37 +619,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
         if (CHEB && go && cheb && !converged && cheb_ok) {
             // Chebyshev iteration for (I + E) x = b on [alo, chi] from (x, r): d_0 = r / theta, then
             //   x += d;  r -= (I + E) d;  rho' = 1 / (2 sigma_1 - rho);  d = rho' rho d + (2 rho' / delta) r        (sigma_1 = theta / delta)
-            // (two-wave geometry: x waits in LDS during this recurrence -- r, d and z are the registers the Neumann loop has for
-            // x, y and z, a fourth vector would spill; only the lanes that write the row out, wave 0 group 0, hold x at all)
             it_f32x2 dv[H];
             float db = rb * itheta, rho0 = delta * itheta;
             const float phi = delta * itheta;
-            const bool xowner = wv == 0 && q == 0;
             auto x_add = [&](const it_f32x2 (&dx)[H], float dxb, float sc) {      // x += sc dx
-                if constexpr (XL) {
-                    if (xowner) {
 #pragma unroll
-                        for (int j = 0; j < P4; ++j) {
-                            f32x4 xo = *reinterpret_cast<f32x4*>(x_lds + r * FPL + 4 * j);
-                            xo += f32x4{dx[2 * j][0], dx[2 * j][1], dx[2 * j + 1][0], dx[2 * j + 1][1]} * sc;
-                            *reinterpret_cast<f32x4*>(x_lds + r * FPL + 4 * j) = xo;
-                        }
-                        if (SPLIT && r == 0) x_lds[16 * FPL] += sc * dxb;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < H; ++j) xv[j] = dx[j] * it_f32x2{sc, sc} + xv[j];
-                    if constexpr (SPLIT) xb = __builtin_fmaf(sc, dxb, xb);
-                }
+                for (int j = 0; j < H; ++j) xv[j] = dx[j] * it_f32x2{sc, sc} + xv[j];
+                if constexpr (SPLIT) xb = __builtin_fmaf(sc, dxb, xb);
             };
-            if constexpr (XL) {
-                if (xowner) {
-#pragma unroll
-                    for (int j = 0; j < P4; ++j)
-                        *reinterpret_cast<f32x4*>(x_lds + r * FPL + 4 * j) = f32x4{xv[2 * j][0], xv[2 * j][1], xv[2 * j + 1][0], xv[2 * j + 1][1]};
-                    if (SPLIT && r == 0) x_lds[16 * FPL] = xb;
-                }
-            }
 #pragma unroll
             for (int j = 0; j < H; ++j) dv[j] = rv[j] * it_f32x2{itheta, itheta};
             for (; napp < kmax;) {
@@ -677,16 +652,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
 #pragma unroll
                 for (int j = 0; j < H; ++j) dv[j] = rv[j] * it_f32x2{alpha, alpha} + dv[j] * it_f32x2{beta, beta};
                 if constexpr (SPLIT) db = alpha * rb + beta * db;
-            }
-            if constexpr (XL) {
-                if (xowner) {                                   // back into the registers the row is written from
-#pragma unroll
-                    for (int j = 0; j < P4; ++j) {
-                        const f32x4 xo = *reinterpret_cast<f32x4*>(x_lds + r * FPL + 4 * j);
-                        xv[2 * j] = it_f32x2{xo[0], xo[1]}; xv[2 * j + 1] = it_f32x2{xo[2], xo[3]};
-                    }
-                    if constexpr (SPLIT) xb = x_lds[16 * FPL];
-                }
             }
         }
         if (converged) {
