@@ -554,6 +554,79 @@ __global__ __launch_bounds__(256) void transform64_kernel(const double* __restri
     }
 }
 
+// The same product on the matrix cores, for widths whose W fits LDS (FP . ldw doubles <= 160 KB: f <= 140): W is copied to LDS once per
+// (persistent) workgroup, every wave then takes 16-row tiles on its own -- the tile's rows as the A operands of
+// v_mfma_f64_16x16x4_f64 straight from global memory (lane (i, k) holds in[row0 + i][4 kk + k]: each row is read once, in
+// 32-byte pieces), the 16-column blocks of W as B operands from LDS (row stride ldw = 16 mod 32 doubles: the four k of a read on
+// disjoint banks), G column blocks at a time so that G accumulators are in flight.  The VALU form above spends 16 FMAs on 2
+// global and 4 LDS loads per step (13 TFLOP/s at f = 129); here the tile costs f4 . nb products and nothing else.
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+template <int KK, int G>
+__global__ __launch_bounds__(512) void transform64m_kernel(const double* __restrict__ in, int64_t m, int f, const double* __restrict__ W,
+                                                           int set_col0_one, double* __restrict__ out, const int64_t* __restrict__ indptr,
+                                                           const int32_t* __restrict__ ctrl, const int32_t* __restrict__ state, int ldw, int nb) {
+    extern __shared__ __attribute__((aligned(16))) double sm64[];
+    if (ctrl[0] == 0) return;
+    const int f4 = (f + 3) >> 2, FP = 4 * f4;
+    for (int i = threadIdx.x; i < FP * ldw; i += 512) {
+        const int k = i / ldw, c = i - k * ldw;
+        sm64[i] = c < FP ? W[(int64_t)k * FP + c] : 0.0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int64_t ntiles = (m + 15) >> 4;
+    const int ngroups = (nb + G - 1) / G;
+    for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
+        const int64_t row0 = tile << 4;
+        // which of this lane's four output rows (row0 + q + 4 v) are written
+        bool ok[4];
+        bool any = false;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int64_t row = row0 + q + 4 * v;
+            ok[v] = row < m;
+            if (ok[v] && indptr) {                               // un-whitening: the low-rank rows and the rows the iteration solved
+                const int64_t d = indptr[row + 1] - indptr[row];
+                ok[v] = (d >= 1 && d <= F64_LR_D) || (state && state[row]);
+            }
+            any |= ok[v];
+        }
+        if (!__builtin_amdgcn_readfirstlane((int)(__ballot(any) != 0))) continue;
+        const int64_t arow = row0 + r;
+        const bool avalid = arow < m;
+        const double* ap = in + (avalid ? arow : 0) * f;
+        double a[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int c = 4 * kk + q;
+            a[kk] = (kk < f4 && c < f && avalid) ? ap[c] : 0.0;
+        }
+        if (set_col0_one && q == 0 && avalid) a[0] = 1.0;
+        for (int g = 0; g < ngroups; ++g) {
+            f64x4_t acc[G];
+#pragma unroll
+            for (int c = 0; c < G; ++c) acc[c] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+            const double* wb = sm64 + q * ldw + 16 * G * g + r;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {                    // (no branch on kk < f4: a[kk] = 0 there and the read stays inside W)
+                const double* wk = wb + 4 * (kk < f4 ? kk : 0) * ldw;
+#pragma unroll
+                for (int c = 0; c < G; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], wk[16 * c], acc[c], 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < G; ++c) {
+                const int col = 16 * (G * g + c) + r;
+                if (col < f) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (ok[v]) out[(row0 + q + 4 * v) * f + col] = acc[c][v];
+                }
+            }
+        }
+    }
+}
+
 // one WAVE per row with 1 .. 32 stored entries.  LDS per wave (doubles): ys [16][36] | ones [16] | panel [2][9 * 16] | dbuf [32] | yv [32] |
 // xs [4] | ev [32] | tv [32] | cv [32] | ib (int) [32]
 #define F64_LR_TEAM_DOUBLES 1080
@@ -827,6 +900,36 @@ static void launch_transform64(const double* in, int64_t m, int f, const double*
                                const int32_t* ctrl, hipStream_t st, const int32_t* state = nullptr) {
     if (m <= 0) return;
     const int f4 = (f + 3) / 4, FP = 4 * f4;
+    {                                               // the matrix-core form where W fits LDS (debug flag 536870912: never)
+        const int nb = (f + 15) / 16;
+        const int ldw = 16 * nb + ((nb & 1) ? 0 : 16);          // 16 mod 32
+        const size_t lds = (size_t)FP * ldw * 8;
+        if (lds <= 160 * 1024 && f4 <= 36 && !(wmf_debug_flags & 536870912)) {
+            int64_t grid = ((m + 15) / 16 + 7) / 8;
+            if (grid > 256) grid = 256;
+#define TM_(KK, G)                                                                                                                     \
+    do {                                                                                                                               \
+        static bool set_ = false;                                                                                                      \
+        if (!set_) {                                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)transform64m_kernel<KK, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            set_ = true;                                                                                                               \
+        }                                                                                                                              \
+        static const char* nm_ = wmf_kname("transform64m_kernel<%d, %d>", KK, G);                                                      \
+        WMF_LAUNCH(nm_, (transform64m_kernel<KK, G>), dim3((unsigned)grid), dim3(512), lds, st, in, m, f, W, set_col0_one, out, indptr, \
+                   ctrl, state, ldw, nb);                                                                                              \
+    } while (0)
+            if (f4 <= 16) TM_(16, 2);
+            else if (f4 == 17) TM_(17, 3);
+            else if (f4 <= 20) TM_(20, 3);
+            else if (f4 <= 24) TM_(24, 3);
+            else if (f4 <= 28) TM_(28, 3);
+            else if (f4 <= 32) TM_(32, 3);
+            else if (f4 == 33) TM_(33, 3);
+            else TM_(36, 3);
+#undef TM_
+            return;
+        }
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)transform64_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
