@@ -13,11 +13,15 @@
 // Geometry (as in wmf_iter.hip): NW waves per row; entry e = 4 NW s + 4 w + q sits in slot s of wave w, lane group q, whose 16
 // lanes r hold FPD consecutive doubles each; NW = 4 for rows of 33 .. 4 NW NS entries, NW = 1 (four independent rows per
 // workgroup) for rows of 1 .. 32 entries.
+#include <type_traits>
 #include "wmf_common.h"
 #include "wmf_internal.h"
 
 #ifndef IT64_TAU
 #define IT64_TAU 0.5
+#endif
+#ifndef IT64_GS
+#define IT64_GS 2                                     /* slots of an application worked on together (4: 8 % slower, 1: the same) */
 #endif
 #ifndef IT64_KMAX
 #define IT64_KMAX 40
@@ -54,8 +58,11 @@ __device__ __forceinline__ double i64_qsum(double v) {
            __builtin_bit_cast(double, ((long long)(int)uh[1] << 32) | (unsigned)(int)ul[1]);
 }
 
+#ifndef IT64_WIDE_WG
+#define IT64_WIDE_WG 2                                /* workgroups per CU asked of the compiler for the f > 128 four-wave form */
+#endif
 template <int NW, int FPD, int NS>
-__global__ __launch_bounds__(256) void solve64it_kernel(const double* __restrict__ V, const double* __restrict__ Y, int f, int bias,
+__global__ __launch_bounds__(256, (NW == 4 && FPD == 9) ? IT64_WIDE_WG : 1) void solve64it_kernel(const double* __restrict__ V, const double* __restrict__ Y, int f, int bias,
                                                         const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                         const double* __restrict__ vals, int64_t n, int dlo, int dhi,
                                                         double* __restrict__ gout, int32_t* __restrict__ state,
@@ -115,23 +122,25 @@ __global__ __launch_bounds__(256) void solve64it_kernel(const double* __restrict
         }
         bool neg = false;
         // ---- totals over the row: z (per-lane partials over this lane's entries) -> sums over the lane groups and the waves
-        auto exchange = [&](double (&z)[FPD], double& s1, double& s2) {
+        auto exchange = [&](double (&z)[FPD], double& s1, double& s2, auto scalars) {       // scalars: pass 0 only (tau, negatives)
+            constexpr bool SC = decltype(scalars)::value;
 #pragma unroll
             for (int j = 0; j < FPD; ++j) z[j] = i64_qsum(z[j]);
-            s1 = i64_qsum(s1);
-            s2 = i64_qsum(s2);
+            if constexpr (SC) { s1 = i64_qsum(s1); s2 = i64_qsum(s2); }
             if constexpr (NW == 4) {
                 if (q == 0) {
 #pragma unroll
                     for (int j = 0; j < FPD; ++j) part[parity][wv][r * FPD + j] = z[j];
-                    if (r == 0) { psc[parity][wv][0] = s1; psc[parity][wv][1] = s2; }
+                    if constexpr (SC) { if (r == 0) { psc[parity][wv][0] = s1; psc[parity][wv][1] = s2; } }
                 }
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < FPD; ++j)
                     z[j] = (part[parity][0][r * FPD + j] + part[parity][1][r * FPD + j]) + (part[parity][2][r * FPD + j] + part[parity][3][r * FPD + j]);
-                s1 = (psc[parity][0][0] + psc[parity][1][0]) + (psc[parity][2][0] + psc[parity][3][0]);
-                s2 = (psc[parity][0][1] + psc[parity][1][1]) + (psc[parity][2][1] + psc[parity][3][1]);
+                if constexpr (SC) {
+                    s1 = (psc[parity][0][0] + psc[parity][1][0]) + (psc[parity][2][0] + psc[parity][3][0]);
+                    s2 = (psc[parity][0][1] + psc[parity][1][1]) + (psc[parity][2][1] + psc[parity][3][1]);
+                }
                 parity ^= 1;
             }
         };
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(256) void solve64it_kernel(const double* __restrict
         double negs = neg ? 1.0 : 0.0;
         tau = i64_row16_sum(tau);
         negs = i64_row16_sum(negs);
-        exchange(bv, tau, negs);
+        exchange(bv, tau, negs, std::true_type{});
         const double nb = norm2(bv);
         // (wave-uniform by construction: every lane holds the same totals)
         bool go = tau <= IT64_TAU && negs == 0.0;
@@ -183,30 +192,30 @@ __global__ __launch_bounds__(256) void solve64it_kernel(const double* __restrict
 #pragma unroll
                 for (int j = 0; j < FPD; ++j) z[j] = 0.0;
 #pragma unroll
-                for (int s4 = 0; s4 < NS; s4 += 4) {                 // four slots at a time: four independent chains (slots past the
-                    if (s4 < ns) {                                   // row's end hold zeros)
-                        double a[4];
+                for (int s2 = 0; s2 < NS; s2 += IT64_GS) {           // IT64_GS slots at a time (independent chains); a group past the row's
+                    if (s2 < ns) {                                   // end is skipped, the empty slots of the last one hold zeros
+                        double a[IT64_GS];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
+                        for (int i = 0; i < IT64_GS; ++i) {
                             a[i] = 0.0;
-                            if (s4 + i < NS) {
+                            if (s2 + i < NS) {
 #pragma unroll
-                                for (int j = 0; j < FPD; ++j) a[i] = __builtin_fma(vb[s4 + i][j], yv[j], a[i]);
+                                for (int j = 0; j < FPD; ++j) a[i] = __builtin_fma(vb[s2 + i][j], yv[j], a[i]);
                             }
                         }
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) a[i] = i64_row16_sum(a[i]);
+                        for (int i = 0; i < IT64_GS; ++i) a[i] = i64_row16_sum(a[i]);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            if (s4 + i < NS) {
-                                const double t = a[i] * wt[s4 + i];
+                        for (int i = 0; i < IT64_GS; ++i) {
+                            if (s2 + i < NS) {
+                                const double t = a[i] * wt[s2 + i];
 #pragma unroll
-                                for (int j = 0; j < FPD; ++j) z[j] = __builtin_fma(t, vb[s4 + i][j], z[j]);
+                                for (int j = 0; j < FPD; ++j) z[j] = __builtin_fma(t, vb[s2 + i][j], z[j]);
                             }
                         }
                     }
                 }
-                exchange(z, u1, u2);
+                exchange(z, u1, u2, std::false_type{});
                 const double nr = norm2(z);
 #pragma unroll
                 for (int j = 0; j < FPD; ++j) { xv[j] = __builtin_fma(sign, z[j], xv[j]); yv[j] = z[j]; }

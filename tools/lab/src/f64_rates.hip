@@ -23,6 +23,36 @@ __global__ __launch_bounds__(256) void rate_kernel(double* out, int iters, doubl
             c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, b, z, 0, 0, 0);
             c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, b, z, 0, 0, 0);
             x0 = c0[0] * 1e-3; x1 = c1[1] * 1e-3; x2 = c2[2] * 1e-3; x3 = c3[3] * 1e-3;
+        } else if (MODE == 4) {         // butterfly sum of a double over 16 lanes through ds_swizzle (LDS pipe) + v_add_f64, 4 chains
+            double* xs[4] = {&x0, &x1, &x2, &x3};
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const long long bb = __builtin_bit_cast(long long, *xs[c]);
+                    int lo, hi;
+                    if (st == 0) { lo = __builtin_amdgcn_ds_swizzle((int)bb, 0x041F); hi = __builtin_amdgcn_ds_swizzle((int)(bb >> 32), 0x041F); }
+                    else if (st == 1) { lo = __builtin_amdgcn_ds_swizzle((int)bb, 0x081F); hi = __builtin_amdgcn_ds_swizzle((int)(bb >> 32), 0x081F); }
+                    else if (st == 2) { lo = __builtin_amdgcn_ds_swizzle((int)bb, 0x101F); hi = __builtin_amdgcn_ds_swizzle((int)(bb >> 32), 0x101F); }
+                    else { lo = __builtin_amdgcn_ds_swizzle((int)bb, 0x201F); hi = __builtin_amdgcn_ds_swizzle((int)(bb >> 32), 0x201F); }
+                    *xs[c] = *xs[c] * 0.25 + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+                }
+            }
+        } else if (MODE == 5) {         // the same butterfly through DPP (VALU only), 4 chains
+            double* xs[4] = {&x0, &x1, &x2, &x3};
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const long long bb = __builtin_bit_cast(long long, *xs[c]);
+                    int lo, hi;
+                    if (st == 0) { lo = __builtin_amdgcn_update_dpp(0, (int)bb, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, (int)(bb >> 32), 0xB1, 0xF, 0xF, true); }
+                    else if (st == 1) { lo = __builtin_amdgcn_update_dpp(0, (int)bb, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, (int)(bb >> 32), 0x4E, 0xF, 0xF, true); }
+                    else if (st == 2) { lo = __builtin_amdgcn_update_dpp(0, (int)bb, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, (int)(bb >> 32), 0x141, 0xF, 0xF, true); }
+                    else { lo = __builtin_amdgcn_update_dpp(0, (int)bb, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, (int)(bb >> 32), 0x140, 0xF, 0xF, true); }
+                    *xs[c] = *xs[c] * 0.25 + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+                }
+            }
         } else if (MODE == 3) {         // 4x4x4 (4 blocks) MFMAs
             x0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, x0, 0, 0, 0);
             x1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, x1, 0, 0, 0);
@@ -48,11 +78,14 @@ static void run(const char* name, int per_iter, int waves_per_simd) {
     hipFree(out);
 }
 int main() {
-    for (int w = 1; w <= 2; ++w) {
+    for (int w = 1; w <= 4; ++w) {
+        if (w == 3) continue;
         run<0>("mfma_f64_16x16x4 (acc chain)", 4, w);
         run<2>("mfma_f64_16x16x4 (zero C)", 4, w);
         run<3>("mfma_f64_4x4x4_4b", 4, w);
         run<1>("v_fma_f64", 8, w);
+        run<4>("16-lane f64 sum, ds_swizzle", 4, w);       // per sum of one double
+        run<5>("16-lane f64 sum, DPP", 4, w);
     }
     return 0;
 }
