@@ -278,7 +278,8 @@ int wmf_profile_reset(void);
  *       131072 f32 Gramian and 262144 f32 row transform for f = 97 .. 144, 524288 f32 S tiles for rows with <= 32 entries,
  *       2097152 f32 MFMA kernel for f > 144 (it does not split rows above 4096 entries), 16777216 the k = 128 heavy-row
  *       kernel with 16-entry groups at one wave per SIMD (instead of 8-entry groups at two), 268435456 no matrix-free
- *       iteration kernel (csrc/wmf_iter.hip): every row above 32 entries is eliminated, as in round 3.
+ *       iteration kernel (csrc/wmf_iter.hip): every row above 32 entries is eliminated, as in round 3, 536870912 the VALU forms
+ *       of the float64 Gramian and row transform (csrc/wmf_f64.hip) instead of the v_mfma_f64_16x16x4_f64 ones.
  * The ablation switches 1 / 2 / 8 (no elimination / no accumulation MFMAs / no tile inverse: results WRONG) exist only
  * in a -DWMF_LAB build; the shipped library returns WMF_EINVAL for them. */
 int wmf_debug_set_flags(int flags);

@@ -107,6 +107,86 @@ __global__ __launch_bounds__(256) void gram64v2_kernel(const double* __restrict_
     }
 }
 
+// The Gramian on the matrix cores (f <= 144): eight waves per workgroup, each with up to PW of the 16 x 16 upper tiles (bi <= bj)
+// of Y~^T Y~; a tile's two operands of v_mfma_f64_16x16x4_f64 are the same kind of fragment -- lane (r, q) holds
+// Y~[row0 + q][16 b + r], for b = bi and b = bj -- read from an LDS image of sixteen rows (row stride 16 mod 32 doubles: the four
+// rows of a read on disjoint banks; fragments straight from global memory made the texture path the bound: 96 eight-byte loads
+// per four rows and workgroup, 13.5 ms at cfg3's size), the next sixteen rows fetched while the products run, one barrier per
+// sixteen rows.  Results leave in the 4 x 4 block layout gram64v2_reduce_kernel sums.  The VALU form above reaches 13 TFLOP/s at f = 129 (LDS operand reads); this one is bound by
+// the products (T tiles per four rows at 31.6 ns each per SIMD: tools/lab/src/f64_rates.hip).
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+template <int PW>
+__global__ __launch_bounds__(512) void gram64m_kernel(const double* __restrict__ Y, int64_t m, int f, int bias, double* __restrict__ partial,
+                                                      int64_t rows_per_block, int nb16, int ldy) {
+    extern __shared__ __attribute__((aligned(16))) double sm64[];      // two images [16][ldy] of sixteen rows of Y~, zero padded
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int f4 = (f + 3) >> 2, nblk = f4 * (f4 + 1) / 2;
+    const int ntile = nb16 * (nb16 + 1) / 2;
+    int bi[PW], bj[PW];
+    bool on[PW];
+#pragma unroll
+    for (int p = 0; p < PW; ++p) {
+        const int tl = wave + 8 * p;
+        on[p] = tl < ntile;
+        int a = 0, rem = on[p] ? tl : 0;
+        while (rem >= nb16 - a) { rem -= nb16 - a; ++a; }           // (scalar: the tile number is wave-uniform)
+        bi[p] = a; bj[p] = a + rem;
+    }
+    f64x4_t acc[PW];
+#pragma unroll
+    for (int p = 0; p < PW; ++p) acc[p] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(m, r0 + rows_per_block);
+    constexpr int LD = 5;                                           // 16 x 144 doubles over 512 threads
+    const int W = 16 * nb16;                                        // columns staged (ldy >= W)
+    double stage[LD];
+    auto fetch = [&](int64_t c0) {
+#pragma unroll
+        for (int k = 0; k < LD; ++k) {
+            const int i = t + 512 * k, e = i / W, c = i - e * W;
+            const int64_t row = c0 + e;
+            const bool ok = e < 16 && row < r1 && c < f;
+            const double v = Y[ok ? row * f + c : r0 * f];
+            stage[k] = ok ? ((bias && c == 0) ? 1.0 : v) : 0.0;
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < LD; ++k) {
+            const int i = t + 512 * k, e = i / W, c = i - e * W;
+            if (e < 16) sm64[(buf * 16 + e) * ldy + c] = stage[k];
+        }
+    };
+    if (r0 < r1) { fetch(r0); put(0); }
+    __syncthreads();
+    int buf = 0;
+    for (int64_t c0 = r0; c0 < r1; c0 += 16) {
+        const bool more = c0 + 16 < r1;
+        if (more) fetch(c0 + 16);
+        const double* ys = sm64 + (buf * 16 + q) * ldy + r;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int p = 0; p < PW; ++p)
+                acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ys[4 * s * ldy + 16 * bi[p]], ys[4 * s * ldy + 16 * bj[p]], acc[p], 0, 0, 0);
+        if (more) put(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    double* out = partial + (int64_t)blockIdx.x * nblk * 16;
+#pragma unroll
+    for (int p = 0; p < PW; ++p) {
+        if (!on[p]) continue;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int gi = 16 * bi[p] + q + 4 * v, gj = 16 * bj[p] + r;
+            const int BI = gi >> 2, BJ = gj >> 2;
+            if (BI < f4 && BJ < f4 && BJ >= BI) out[(int64_t)(BI * f4 - BI * (BI - 1) / 2 + (BJ - BI)) * 16 + 4 * (gi & 3) + (gj & 3)] = acc[p][v];
+        }
+    }
+}
+
 // G = sum of the partial blocks (fixed order: reproducible) + lambda I, both triangles
 __global__ __launch_bounds__(256) void gram64v2_reduce_kernel(const double* __restrict__ partial, int nwg, int f, double lambda,
                                                               double* __restrict__ G) {
@@ -560,7 +640,6 @@ __global__ __launch_bounds__(256) void transform64_kernel(const double* __restri
 // 32-byte pieces), the 16-column blocks of W as B operands from LDS (row stride ldw = 16 mod 32 doubles: the four k of a read on
 // disjoint banks), G column blocks at a time so that G accumulators are in flight.  The VALU form above spends 16 FMAs on 2
 // global and 4 LDS loads per step (13 TFLOP/s at f = 129); here the tile costs f4 . nb products and nothing else.
-typedef double f64x4_t __attribute__((ext_vector_type(4)));
 template <int KK, int G>
 __global__ __launch_bounds__(512) void transform64m_kernel(const double* __restrict__ in, int64_t m, int f, const double* __restrict__ W,
                                                            int set_col0_one, double* __restrict__ out, const int64_t* __restrict__ indptr,
@@ -863,6 +942,16 @@ static void launch_gram64(const double* Y, int64_t m, int f, int bias, double la
     }
     static const char* nmg = wmf_kname("gram64v2_kernel<%d>", NB);
     const int64_t rpb = (m + nwg - 1) / nwg;
+    const int nb16 = (f + 15) / 16, pw = (nb16 * (nb16 + 1) / 2 + 7) / 8, ldy = 16 * nb16 + ((nb16 & 1) ? 0 : 16);
+    if (pw <= 6 && !(wmf_debug_flags & 536870912)) {        // the matrix-core form (f <= 144)
+#define GM_(PW)                                                                                                            \
+    case PW: {                                                                                                             \
+        static const char* nm_ = wmf_kname("gram64m_kernel<%d>", PW);                                                      \
+        WMF_LAUNCH(nm_, (gram64m_kernel<PW>), dim3(nwg), dim3(512), (size_t)2 * 16 * ldy * 8, st, Y, m, f, bias, partial, rpb, nb16, ldy); \
+    } break;
+        switch (pw) { GM_(1) GM_(2) GM_(3) GM_(4) GM_(5) GM_(6) }
+#undef GM_
+    } else
     WMF_LAUNCH(nmg, (gram64v2_kernel<NB>), dim3(nwg), dim3(256), lds_g, st, Y, m, f, bias, partial, rpb);
     const int nel = f64_blocks(f, false) * 16;
     WMF_LAUNCH("gram64v2_reduce_kernel", gram64v2_reduce_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, partial, nwg, f,

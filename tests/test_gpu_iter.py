@@ -147,7 +147,8 @@ def test_float64_iteration_against_the_float64_oracle(k, bias):
     """The float64 form of the iteration (csrc/wmf_iter64.hip, inside wmf_half_step_f64 -- the reference's cores > 1 variants,
     wmf_model.py:242-309): rows of 1 .. 32 entries (one wave per row) and of 33 .. 256 / 192 / 144 entries (four waves)
     against a LARGE fixed side, so that tr E is small and the series runs; 1e-10 of oracle.solve_row like every float64 test, and
-    the same rows with the iteration switched off (debug flag 268435456: blocked Cholesky / low-rank kernels) agree to 1e-12."""
+    the same rows with the iteration switched off (debug flag 268435456: blocked Cholesky / low-rank kernels) agree to 1e-12, and so
+    do the matrix-core forms of the Gramian and the row transform with their VALU forms (debug flag 536870912)."""
     from recmodel_amd import _lib
     from recmodel_amd.engine import HipKernels
     f = k + int(bias)
@@ -170,7 +171,7 @@ def test_float64_iteration_against_the_float64_oracle(k, bias):
     fail = torch.zeros(4, dtype=torch.int32, device=dev)
     outs = []
     lib = _lib.load()
-    for flags in (0, 268435456):
+    for flags in (0, 268435456, 536870912):
         out = torch.empty(n_rows, f, dtype=torch.float64, device=dev)
         try:
             lib.wmf_debug_set_flags(flags)
@@ -193,5 +194,7 @@ def test_float64_iteration_against_the_float64_oracle(k, bias):
         want = orc.solve_row(G, Gy[idx], np.arange(hi - lo), ww)
         worst = max(worst, np.linalg.norm(outs[0][u] - want) / np.linalg.norm(want))
     both = np.linalg.norm(outs[0] - outs[1], axis=1) / np.linalg.norm(outs[1], axis=1)
-    record_error(f"iter64[k={k},bias={int(bias)}]", worst_row=float(worst), vs_direct_kernels=float(both.max()))
-    assert worst <= 1e-10 and both.max() <= 1e-12, (worst, both.max())
+    dense = np.linalg.norm(outs[0] - outs[2], axis=1) / np.linalg.norm(outs[2], axis=1)
+    record_error(f"iter64[k={k},bias={int(bias)}]", worst_row=float(worst), vs_direct_kernels=float(both.max()),
+                 vs_valu_dense_forms=float(dense.max()))
+    assert worst <= 1e-10 and both.max() <= 1e-12 and dense.max() <= 1e-12, (worst, both.max(), dense.max())
