@@ -23,6 +23,12 @@
 #ifndef IT64_GS
 #define IT64_GS 2                                     /* slots of an application worked on together (4: 8 % slower, 1: the same) */
 #endif
+#ifndef IT64_BETA
+#define IT64_BETA 1.5                                 /* the interval's width in units of the probe |E b| / |b| */
+#endif
+#ifndef IT64_CHEB
+#define IT64_CHEB 1                                   /* 0: the plain series at every width */
+#endif
 #ifndef IT64_KMAX
 #define IT64_KMAX 40
 #endif
@@ -69,6 +75,7 @@ __global__ __launch_bounds__(256, (NW == 4 && FPD == 9) ? IT64_WIDE_WG : 1) void
                                                         const int32_t* __restrict__ ctrl) {
     constexpr int EPS = 4 * NW, TEAMS = 4 / NW;                 // entries per slot; rows a workgroup works on at once
     constexpr int FEAT = 16 * FPD;
+    constexpr bool CHEB = IT64_CHEB && FPD <= 5;                  // (the wider forms have no registers for a third vector)
     __shared__ double part[2][4][FEAT];                          // cross-wave partial sums (NW = 4), two buffers
     __shared__ double psc[2][4][4];
     if (ctrl[0] == 0) return;                                    // no whitened factors this half step (wmf_f64.hip)
@@ -184,44 +191,87 @@ __global__ __launch_bounds__(256, (NW == 4 && FPD == 9) ? IT64_WIDE_WG : 1) void
         double xv[FPD], yv[FPD];
 #pragma unroll
         for (int j = 0; j < FPD; ++j) { xv[j] = bv[j]; yv[j] = bv[j]; }
-        if (go) {
-            const double stop = 4.9e-32 * nb;                    // (2^-52)^2 |b|^2
-            double sign = -1.0;
-            for (int k = 0; k < IT64_KMAX; ++k) {
-                double z[FPD], u1 = 0.0, u2 = 0.0;
+        // z = E y: pass A (the entries' dots with y, summed over the 16 lanes of a group), pass B, the totals over groups and waves
+        auto apply = [&](const double (&y)[FPD], double (&z)[FPD]) {
+            double u1 = 0.0, u2 = 0.0;
 #pragma unroll
-                for (int j = 0; j < FPD; ++j) z[j] = 0.0;
+            for (int j = 0; j < FPD; ++j) z[j] = 0.0;
 #pragma unroll
-                for (int s2 = 0; s2 < NS; s2 += IT64_GS) {           // IT64_GS slots at a time (independent chains); a group past the row's
-                    if (s2 < ns) {                                   // end is skipped, the empty slots of the last one hold zeros
-                        double a[IT64_GS];
+            for (int s2 = 0; s2 < NS; s2 += IT64_GS) {               // IT64_GS slots at a time (independent chains); a group past the row's
+                if (s2 < ns) {                                       // end is skipped, the empty slots of the last one hold zeros
+                    double a[IT64_GS];
 #pragma unroll
-                        for (int i = 0; i < IT64_GS; ++i) {
-                            a[i] = 0.0;
-                            if (s2 + i < NS) {
+                    for (int i = 0; i < IT64_GS; ++i) {
+                        a[i] = 0.0;
+                        if (s2 + i < NS) {
 #pragma unroll
-                                for (int j = 0; j < FPD; ++j) a[i] = __builtin_fma(vb[s2 + i][j], yv[j], a[i]);
-                            }
+                            for (int j = 0; j < FPD; ++j) a[i] = __builtin_fma(vb[s2 + i][j], y[j], a[i]);
                         }
+                    }
 #pragma unroll
-                        for (int i = 0; i < IT64_GS; ++i) a[i] = i64_row16_sum(a[i]);
+                    for (int i = 0; i < IT64_GS; ++i) a[i] = i64_row16_sum(a[i]);
 #pragma unroll
-                        for (int i = 0; i < IT64_GS; ++i) {
-                            if (s2 + i < NS) {
-                                const double t = a[i] * wt[s2 + i];
+                    for (int i = 0; i < IT64_GS; ++i) {
+                        if (s2 + i < NS) {
+                            const double t = a[i] * wt[s2 + i];
 #pragma unroll
-                                for (int j = 0; j < FPD; ++j) z[j] = __builtin_fma(t, vb[s2 + i][j], z[j]);
-                            }
+                            for (int j = 0; j < FPD; ++j) z[j] = __builtin_fma(t, vb[s2 + i][j], z[j]);
                         }
                     }
                 }
-                exchange(z, u1, u2, std::false_type{});
-                const double nr = norm2(z);
+            }
+            exchange(z, u1, u2, std::false_type{});
+        };
+        if (go) {
+            const double stop = 4.9e-32 * nb;                    // (2^-52)^2 |b|^2
+            double z[FPD];
+            apply(yv, z);                                        // the first term of the series, and the probe of ||E||
+            double nr = norm2(z);
+            if (nr * tau * tau <= stop) {                        // x = b - E b: the next term would be <= tau |z|
+                converged = true;
 #pragma unroll
-                for (int j = 0; j < FPD; ++j) { xv[j] = __builtin_fma(sign, z[j], xv[j]); yv[j] = z[j]; }
-                if (nr * tau * tau <= stop) { converged = true; break; }      // the next term would be <= tau |z|
-                if (!(nr == nr)) break;                          // NaN: leave the row to the direct kernel
-                sign = -sign;
+                for (int j = 0; j < FPD; ++j) xv[j] -= z[j];
+            } else if constexpr (CHEB) {
+                // Chebyshev recurrence for (I + E) x = b on [1, 1 + beta] (Saad, Iterative Methods, alg. 12.1), beta = 1.5 |E b| / |b|
+                // capped by tr E: E is positive semi-definite here (no negative weight) and b = V_u^T p leans on its dominant
+                // directions, so the probe is close to ||E|| from below.  An optimistic beta is safe: for an eigenvalue lambda
+                // beyond it the error still contracts while lambda < 2 + beta, and tr E <= IT64_TAU bounds them all; x, r are
+                // updated with the same d, so r stays the residual of x whatever the coefficients are (rcp is approximate).
+                const double rho1 = __builtin_sqrt(nr / nb);
+                const double beta = fmin(tau, fmax(IT64_BETA * rho1, 1e-9));
+                const double theta = 1.0 + 0.5 * beta, idelta = 2.0 / beta, sigma = theta * idelta;
+                double rho = 1.0 / sigma, rv[FPD], dv[FPD];
+                const double itheta = 1.0 / theta;
+#pragma unroll
+                for (int j = 0; j < FPD; ++j) { rv[j] = -z[j]; dv[j] = rv[j] * itheta; }       // x0 = b, r0 = b - (b + E b)
+                for (int k = 1; k < IT64_KMAX; ++k) {
+#pragma unroll
+                    for (int j = 0; j < FPD; ++j) xv[j] += dv[j];
+                    apply(dv, z);
+#pragma unroll
+                    for (int j = 0; j < FPD; ++j) rv[j] -= dv[j] + z[j];
+                    nr = norm2(rv);
+                    if (nr <= 16.0 * stop) { converged = true; break; }        // |x - x*| <= |r| (the matrix is >= I): four ulps of |b|
+                    if (!(nr == nr)) break;                      // NaN: leave the row to the direct kernel
+                    const double rho_n = __builtin_amdgcn_rcp(2.0 * sigma - rho);
+                    const double c1 = rho_n * rho, c2 = 2.0 * rho_n * idelta;
+#pragma unroll
+                    for (int j = 0; j < FPD; ++j) dv[j] = __builtin_fma(c1, dv[j], c2 * rv[j]);
+                    rho = rho_n;
+                }
+            } else {
+                double sign = 1.0;
+#pragma unroll
+                for (int j = 0; j < FPD; ++j) { xv[j] -= z[j]; yv[j] = z[j]; }
+                for (int k = 1; k < IT64_KMAX; ++k) {
+                    apply(yv, z);
+                    nr = norm2(z);
+#pragma unroll
+                    for (int j = 0; j < FPD; ++j) { xv[j] = __builtin_fma(sign, z[j], xv[j]); yv[j] = z[j]; }
+                    if (nr * tau * tau <= stop) { converged = true; break; }  // the next term would be <= tau |z|
+                    if (!(nr == nr)) break;
+                    sign = -sign;
+                }
             }
         }
         if (converged) {
