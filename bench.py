@@ -669,8 +669,8 @@ def main():
         for tag, r in [(args.config, out)] + [(n, r) for n, r in (also or {}).items() if "kernels" in r]:
             print(f"[bench] {tag}: {r['ms_per_step']:.3f} ms per iteration", file=sys.stderr)
             for e in r["kernels"][:8]:
-                print(f"[bench]   {e['kernel']:<52} {e['half_step']:<6} avg {e['avg_ms']:8.4f} ms  frac "
-                      f"{e.get('frac', float('nan')):.3f}", file=sys.stderr)
+                frac = f"frac {e['frac']:.3f}" if e.get("frac") is not None else "(no HBM / MFMA model)"
+                print(f"[bench]   {e['kernel']:<52} {e['half_step']:<6} avg {e['avg_ms']:8.4f} ms  {frac}", file=sys.stderr)
         print(f"[bench] full record: {detail_path}", file=sys.stderr, flush=True)
         line = compact_line(out, os.path.relpath(detail_path, ROOT) if not detail_path.startswith("(") else detail_path)
         sys.stdout.flush()
