@@ -92,6 +92,19 @@ int wmf_factorize(const double* G_sum, int f, int ld, double lambda,
  * where the (f + 3)-float row at its 528-byte stride touched five lines for 4.03 lines of data), and col0_out, then
  * REQUIRED, is float[2 m]: col0_out[2 r] = feature f - 1, col0_out[2 r + 1] = the bias.  out may not alias in there.
  * wmf_solve_rows / wmf_accumulate_rows take the two arrays as their V and bias_fixed. */
+/* ROLLED COORDINATES (round 4; wmf_rolled_layout_supported(f, ld) != 0: bias models with a 128-float body, k = 128).  With a
+ * bias model whitened feature 0 is the same number for every row -- in~'s column of ones times an upper-triangular W_white -- so
+ * a caller may keep the whitened side in coordinates rolled by one: feature c at position c - 1, feature 0 last.
+ *   set_col0_one = 3  whitening as above (split layout), written in rolled coordinates: the border feature of the pairs is
+ *                     then that constant, and the 32 bits of the row's bias replace the last mantissa bit of body positions
+ *                     8 j, 8 j + 1 (j < 16; each value moves by at most one ulp).  The row kernels that hold eight consecutive
+ *                     features per lane rebuild the bias from the row they gathered: the pairs -- 8 bytes that cost a whole
+ *                     128-byte line per stored entry, 1.0 - 1.9 ms of configs[2]'s item half step -- are not fetched at all.
+ *   set_col0_one = 4  the input is in rolled coordinates (the g of wmf_solve_rows_ex(WMF_SOLVE_ROLLED)): out = in . W as for 0.
+ * Every kernel accepts such a V / pairs (it is a permutation of the features); wmf_solve_rows_ex must be told, because the
+ * kernels that skip the pairs rely on both properties. */
+int wmf_rolled_layout_supported(int f, int ld);
+
 int wmf_row_transform(const float* in, int64_t m, int f, int ld, const float* W,
                       int set_col0_one, float* out, float* col0_out, void* stream);
 /* Floats per row of the whitened fixed side that wmf_row_transform(set_col0_one = bias) writes and the row kernels read:
@@ -130,6 +143,12 @@ int  wmf_plan_iter_stats(wmf_plan* p, int64_t* out4);
 int wmf_solve_rows(const wmf_plan* plan, const float* V, const float* bias_fixed,
                    const int64_t* indptr, const int32_t* indices, const float* values,
                    int64_t n, int f, int ld, float* g, int32_t* fail_count, void* stream);
+/* The same, with flags: WMF_SOLVE_ROLLED = V and bias_fixed come from wmf_row_transform(set_col0_one = 3) (see there); g is
+ * then in rolled coordinates: follow with wmf_row_transform(g, W_unwhite, set_col0_one = 4). */
+#define WMF_SOLVE_ROLLED 1
+int wmf_solve_rows_ex(const wmf_plan* plan, const float* V, const float* bias_fixed,
+                   const int64_t* indptr, const int32_t* indices, const float* values,
+                   int64_t n, int f, int ld, float* g, int32_t* fail_count, int flags, void* stream);
 
 /* Sum over the stored, non-zero entries of a CSR "utility" matrix of (value - predict(u, i))^2
  * and |value - predict(u, i)| -- RecModel.eval_prec (base_model.py:163-176) with WMF.predict
@@ -279,7 +298,8 @@ int wmf_profile_reset(void);
  *       2097152 f32 MFMA kernel for f > 144 (it does not split rows above 4096 entries), 16777216 the k = 128 heavy-row
  *       kernel with 16-entry groups at one wave per SIMD (instead of 8-entry groups at two), 268435456 no matrix-free
  *       iteration kernel (csrc/wmf_iter.hip): every row above 32 entries is eliminated, as in round 3, 536870912 the VALU forms
- *       of the float64 Gramian and row transform (csrc/wmf_f64.hip) instead of the v_mfma_f64_16x16x4_f64 ones.
+ *       of the float64 Gramian and row transform (csrc/wmf_f64.hip) instead of the v_mfma_f64_16x16x4_f64 ones, 1073741824
+ *       wmf_rolled_layout_supported() answers 0 (callers then keep the plain split layout).
  * The ablation switches 1 / 2 / 8 (no elimination / no accumulation MFMAs / no tile inverse: results WRONG) exist only
  * in a -DWMF_LAB build; the shipped library returns WMF_EINVAL for them. */
 int wmf_debug_set_flags(int flags);

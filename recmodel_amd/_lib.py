@@ -36,6 +36,8 @@ SIGNATURES = {
     "wmf_plan_stats": (c_int, [c_vp, c_vp]),
     "wmf_plan_iter_stats": (c_int, [c_vp, c_vp]),
     "wmf_solve_rows": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    "wmf_solve_rows_ex": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
+    "wmf_rolled_layout_supported": (c_int, [c_int, c_int]),
     "wmf_eval_workspace_bytes": (c_i64, []),
     "wmf_eval_sqerr": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "wmf_predict_pairs": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),

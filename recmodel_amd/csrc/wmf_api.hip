@@ -355,11 +355,25 @@ int wmf_plan_iter_stats(wmf_plan* p, int64_t* out4) {
     return WMF_OK;
 }
 
+int wmf_rolled_layout_supported(int f, int ld) { return (check_shape(f, ld) == 0 && wmf_rolled_layout(f, ld)) ? 1 : 0; }
+
 int wmf_solve_rows(const wmf_plan* plan, const float* V, const float* bias_fixed, const int64_t* indptr,
                    const int32_t* indices, const float* values, int64_t n, int f, int ld, float* g,
                    int32_t* fail_count, void* stream) {
+    return wmf_solve_rows_ex(plan, V, bias_fixed, indptr, indices, values, n, f, ld, g, fail_count, 0, stream);
+}
+
+int wmf_solve_rows_ex(const wmf_plan* plan, const float* V, const float* bias_fixed, const int64_t* indptr,
+                      const int32_t* indices, const float* values, int64_t n, int f, int ld, float* g,
+                      int32_t* fail_count, int flags, void* stream) {
     int rc = check_shape(f, ld);
     if (rc) return rc;
+    if (flags & ~WMF_SOLVE_ROLLED) { wmf_set_error("wmf_solve_rows_ex: unknown flags %d", flags); return WMF_EINVAL; }
+    if ((flags & WMF_SOLVE_ROLLED) && (!bias_fixed || !wmf_rolled_layout(f, ld))) {
+        wmf_set_error("wmf_solve_rows_ex: WMF_SOLVE_ROLLED needs bias_fixed and wmf_rolled_layout_supported(f=%d, ld=%d)", f, ld);
+        return WMF_EINVAL;
+    }
+    if (plan) plan->rolled = (flags & WMF_SOLVE_ROLLED) ? 1 : 0;
     if (!plan || !V || !indptr || !g || !fail_count) { wmf_set_error("wmf_solve_rows: null pointer"); return WMF_EINVAL; }
     if (bias_fixed && !plan->bias) { wmf_set_error("wmf_solve_rows: bias_fixed given, but the plan was created with bias = 0"); return WMF_EINVAL; }
     if (plan->n != n || plan->f != f) { wmf_set_error("wmf_solve_rows: plan was built for n=%lld f=%d", (long long)plan->n, plan->f); return WMF_EINVAL; }

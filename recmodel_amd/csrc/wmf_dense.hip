@@ -850,9 +850,14 @@ __global__ __launch_bounds__(512) void transform6_kernel(const float* __restrict
     const int tid = threadIdx.x;
     for (int e = tid; e < NKC * NFB; e += 512) nz[e] = 0;
     __syncthreads();
+    // set_col0_one == 3 / 4: the ROLLED whitened coordinates (include/wmf_hip.h) -- whitened feature c lives at position c - 1 and
+    // feature 0 at position f - 1: column n of the matrix in LDS is column n + 1 of W when whitening (3), its row k is row k + 1
+    // of W when the input is in those coordinates (4, the un-whitening); both mod f
+    const bool roll_n = set_col0_one == 3, roll_k = set_col0_one == 4;
     for (int e = tid; e < NP * KS; e += 512) {
         const int n = e / KS, k = e % KS;
-        const float v = (k < f && n < f) ? W[k * ld + n] : 0.f;
+        const int ns = (roll_n && n < f) ? (n + 1 == f ? 0 : n + 1) : n, ks = (roll_k && k < f) ? (k + 1 == f ? 0 : k + 1) : k;
+        const float v = (k < f && n < f) ? W[ks * ld + ns] : 0.f;
         const __bf16 h = (__bf16)v;
         const float r1 = v - (float)h;
         const __bf16 md = (__bf16)r1;
@@ -885,9 +890,12 @@ __global__ __launch_bounds__(512) void transform6_kernel(const float* __restrict
             x[2 * c + 1] = irow[min(8 * c + 2 * q + 1, nch - 1)];
         }
     };
+    const bool in_one = set_col0_one >= 1 && set_col0_one <= 3;      // column 0 of the input reads as 1 (whitening of a bias model)
+    const bool sp = set_col0_one == 2 || set_col0_one == 3;          // split layout: packed body rows of f - 1 floats + the pairs
     auto block = [&](int64_t blk, float4 (&xc)[2 * NKC]) {
         const int64_t row = blk * 16 + r;
         const bool rok = row < m;
+        float bias_of_row = 0.f;                                     // (lanes q = 0: the bias of row blk 16 + r)
         f32x4 acc[NFB];
 #pragma unroll
         for (int nb = 0; nb < NFB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -899,8 +907,9 @@ __global__ __launch_bounds__(512) void transform6_kernel(const float* __restrict
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (!(k0 + e < f)) xe[e] = 0.f;
             }
-            if (c == 0 && set_col0_one && q == 0) {
-                if (rok && col0_out) col0_out[set_col0_one == 2 ? 2 * row + 1 : row] = xe[0];      // (2: the split layout's pairs)
+            if (c == 0 && in_one && q == 0) {
+                if (rok && col0_out) col0_out[sp ? 2 * row + 1 : row] = xe[0];                     // (split layout: the pairs)
+                bias_of_row = xe[0];
                 xe[0] = 1.f;
             }
             bf16x8_t ah, am, al;
@@ -933,16 +942,23 @@ __global__ __launch_bounds__(512) void transform6_kernel(const float* __restrict
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int64_t orow = blk * 16 + 4 * q + reg;
+            // (3) the bias of the output row, for its bits: it sits in lane 4 q + reg (q = 0 there)
+            const unsigned bbits = set_col0_one == 3 ? (unsigned)__builtin_amdgcn_ds_bpermute((4 * q + reg) * 4, __builtin_bit_cast(int, bias_of_row)) : 0u;
             if (orow < m) {
-                // split layout (set_col0_one == 2): packed body rows of f - 1 floats, feature f - 1 goes to the pairs
-                const bool sp = set_col0_one == 2;
+                // split layout: packed body rows of f - 1 floats, feature f - 1 goes to the pairs
                 const int wid = sp ? f - 1 : ld;
                 float* o = out + orow * (int64_t)wid;
 #pragma unroll
                 for (int nb = 0; nb < NFB; ++nb) {
                     const int col = 16 * nb + r;
-                    if (col < wid) o[col] = acc[nb][reg];
-                    else if (sp && col == f - 1) col0_out[2 * orow] = acc[nb][reg];
+                    float v = acc[nb][reg];
+                    // (3) bit 2 (col / 8) + col % 8 of the row's bias replaces the last mantissa bit of body positions 8 j, 8 j + 1
+                    // (j < 16): the row kernels that hold 8 consecutive features per lane rebuild the bias from the row they
+                    // gathered instead of fetching the pair (csrc/wmf_iter.hip); the value moves by at most one ulp
+                    if (set_col0_one == 3 && col < 128 && (col & 7) < 2)
+                        v = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, v) & ~1u) | ((bbits >> (2 * (col >> 3) + (col & 7))) & 1u));
+                    if (col < wid) o[col] = v;
+                    else if (sp && col == f - 1) col0_out[2 * orow] = v;
                 }
             }
         }
@@ -1031,9 +1047,14 @@ int wmf_launch_transform(const float* in, int64_t m, int f, int ld, const float*
                          float* col0_out, hipStream_t st) {
     if (m <= 0) return 0;
     const int nfb = (f + 15) / 16;
-    // set_col0_one == 2 inside the kernels: the split layout (wmf_internal.h) -- `out` is the packed body, col0_out the pairs
-    set_col0_one = set_col0_one ? (wmf_split_layout(f, ld) ? 2 : 1) : 0;
-    if (set_col0_one == 2 && (!col0_out || in == out)) return -3;
+    // set_col0_one == 2 inside the kernels: the split layout (wmf_internal.h) -- `out` is the packed body, col0_out the pairs;
+    // 3 / 4 (callers' values, wmf_rolled_layout_supported): the rolled coordinates, transform6_kernel only
+    if (set_col0_one == 3 || set_col0_one == 4) {
+        if (!wmf_rolled_layout(f, ld)) return -1;
+    } else {
+        set_col0_one = set_col0_one ? (wmf_split_layout(f, ld) ? 2 : 1) : 0;
+    }
+    if ((set_col0_one == 2 || set_col0_one == 3) && (!col0_out || in == out)) return -3;
     switch (nfb) {
 #define C(N) case N: launch_transform_nfb<N>(in, m, f, ld, W, set_col0_one, out, col0_out, st); break;
         C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)

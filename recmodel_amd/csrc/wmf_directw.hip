@@ -299,7 +299,7 @@ static void launch_directw_nfb(const wmf_plan* pl, const float* V, const float* 
     const int64_t n_iter = wmf_iter_rows(pl, f, ld, side != nullptr);
     if (n_iter > 0)
         (void)wmf_launch_iter(rows, n_iter, V, side, indptr, indices, vals, f, ld, g, pl->iter_bounce_rows, pl->fallback_count + 1,
-                              pl->iter_stats, pl->iter_info, st);
+                              pl->iter_stats, pl->iter_info, st, (side && pl->rolled) ? 1 : 0);
     // two launches of the elimination kernel: the rows that were never candidates (count on the host), then the bounced ones
     // (count on the device; the grid is sized for the list's capacity and exits at once when the list is empty)
     for (int pass = 0; pass < 2; ++pass) {

@@ -21,6 +21,7 @@ struct wmf_plan {
     int64_t count8, nnz8;      // rows of the first bin with at most 8 entries (and their entries); they come first in rows[WMF_BIN_LOW16]
     bool bias;                 // created for a biased model: w_eff is allocated (unless split)
     bool split;                // latched at creation: the whitened fixed side comes in the split layout (no w_eff needed)
+    mutable int rolled;        // this solve's V / pairs are in the rolled coordinates with the bias bits (wmf_solve_rows_ex; set per call)
     int64_t nnz[WMF_NBINS];    // stored entries per bin
     int32_t* rows[WMF_NBINS];  // device: row ids of each bin (slices of rows_all)
     int32_t* rows_all;         // device: n row ids grouped by bin
@@ -100,8 +101,13 @@ int wmf_launch_wide(const int32_t* rows, int64_t count, const float* V, const fl
 int wmf_iter_dmax(int f, int ld, int split);
 int wmf_launch_iter(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
                     const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* bounce_rows,
-                    int32_t* bounce_count, unsigned long long* stats, const void* info, hipStream_t st);
+                    int32_t* bounce_count, unsigned long long* stats, const void* info, hipStream_t st, int lsb = 0);
 static inline bool wmf_iter_enabled() { return !(wmf_debug_flags & 268435456); }
+// The rolled whitened coordinates with the bias in the body's last mantissa bits (include/wmf_hip.h, wmf_row_transform modes 3 / 4,
+// wmf_solve_rows_ex): bias models whose packed body is 128 floats (k = 128), transform6_kernel and the iteration kernels only
+static inline bool wmf_rolled_layout(int f, int ld) {
+    return f == 129 && wmf_split_layout(f, ld) && !(wmf_debug_flags & 262144) && !(wmf_debug_flags & 1073741824);
+}
 // candidates of this call: none when the iteration is switched off, or when the call's layout (ld, split) is not the one the
 // plan sorted its rows for (a caller with its own leading dimension: the kernel's register slots would not hold the rows)
 static inline int64_t wmf_iter_rows(const wmf_plan* pl, int f, int ld, bool split) {

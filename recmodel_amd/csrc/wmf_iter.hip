@@ -99,7 +99,10 @@ __device__ __forceinline__ void it_tie(float& a) { asm volatile("" : "+v"(a)::"m
 // workgroup by LDS-DMA while this row is iterated on -- no registers, no wait until the row switch, where a wave copies its
 // own entries from LDS to registers.  Without it a row switch exposes one memory latency per row (measured at configs[2]:
 // 13.5 ms, of which 3 ms go when every gather hits the cache).
-template <int NW, int FPL, int NS, bool SPLIT, bool FULL, int OCC, bool DMA>
+// LSB (split layout at 128 body floats, wmf_solve_rows_ex): the whitened side is in the ROLLED coordinates -- its border feature is
+// the same number for every row (side[0]) -- and the fixed side's bias rides in the last mantissa bits of body features 8 j, 8 j + 1
+// (wmf_row_transform mode 3): nothing is fetched from the pairs, whose 8 bytes cost a whole 128-byte line per stored entry.
+template <int NW, int FPL, int NS, bool SPLIT, bool FULL, int OCC, bool DMA, bool LSB = false>
 __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                                  const float* __restrict__ V, const float* __restrict__ side,
                                                                  const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
     constexpr bool CHEB = NW != 2;
     using L = ItLds<NW, FPL>;
     static_assert(!DMA || (NW == 4 && FULL), "DMA variant: four waves, whole pieces");
+    static_assert(!LSB || (SPLIT && FULL && FPL == 8), "bias bits: two per lane of eight features");
     // DMA: [exchange buffers | ring: wave, slot, piece -> 1 KB (lane l at 16 l) | meta: wave -> weights, border, bias (64 dwords each)]
     constexpr int RING_OFF = L::EXCH * 4, META_OFF = RING_OFF + NW * NS * P4 * 1024;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
@@ -126,6 +130,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
     const int r = lane & 15, q = lane >> 4;
     const int ldv = FULL ? 16 * FPL : (SPLIT ? f - 1 : ld);   // floats between gathered rows (split layout: the packed body)
     const float m0 = (r == 0) ? 1.f : 0.f;              // the border feature is counted by one lane of a group
+    const float cb = LSB ? side[0] : 0.f;               // LSB: every row's border value
+    // LSB: the 32 bits of an entry's bias, two from each of the 16 lanes that hold its row (features 8 r, 8 r + 1), or-ed together
+    auto lsb_bias = [&](const it_f32x2& v0) {
+        int b = ((it_bits(v0[0]) & 1) | ((it_bits(v0[1]) & 1) << 1)) << (2 * r);
+        b |= __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+        b |= __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+        b |= __builtin_amdgcn_update_dpp(0, b, 0x141, 0xF, 0xF, true);     // row_half_mirror
+        b |= __builtin_amdgcn_update_dpp(0, b, 0x140, 0xF, 0xF, true);     // row_mirror
+        return it_flt(b);
+    };
     // 16-byte pieces of this lane that lie inside a row (f not a multiple of 64: the last lanes have fewer, or none)
     bool pin[P4];
 #pragma unroll
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
             const int nsn = (dd + EPS - 1) / EPS;
             int idl[NS];
             slot_ids(ic, idl);
-            int idm = SPLIT ? meta_id(ic) : 0;
+            int idm = (SPLIT && !LSB) ? meta_id(ic) : 0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(idl[s]));
             asm volatile("" : "+v"(idm));
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
             if (lane < 4 * NS) {
                 const int e = EPS * (lane >> 2) + 4 * wv + (lane & 3);
                 __builtin_amdgcn_global_load_lds((it_gptr)(vals + l + (e < dd ? e : 0)), (it_lptr)(dyn_lds + META_OFF + wv * 768), 4, 0, 0);
-                if constexpr (SPLIT) {
+                if constexpr (SPLIT && !LSB) {
                     __builtin_amdgcn_global_load_lds((it_gptr)(side + 2 * (int64_t)idm), (it_lptr)(dyn_lds + META_OFF + wv * 768 + 256), 4, 0, 0);
                     __builtin_amdgcn_global_load_lds((it_gptr)(side + 2 * (int64_t)idm + 1), (it_lptr)(dyn_lds + META_OFF + wv * 768 + 512), 4, 0, 0);
                 }
@@ -272,7 +286,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
                         vb[s][2 * j + 1] = it_f32x2{piece[2], piece[3]};
                     });
                     wt[s] = it_ds_read32<16 * s>(meta_rd);
-                    if constexpr (SPLIT) { vbd[s] = it_ds_read32<256 + 16 * s>(meta_rd); bsv[s] = it_ds_read32<512 + 16 * s>(meta_rd); }
+                    if constexpr (SPLIT && !LSB) { vbd[s] = it_ds_read32<256 + 16 * s>(meta_rd); bsv[s] = it_ds_read32<512 + 16 * s>(meta_rd); }
+                    if constexpr (LSB) { vbd[s] = cb; bsv[s] = 0.f; }
                 }
             });
             it_lgkm_wait();
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
 #pragma unroll
                 for (int j = 0; j < H; ++j) asm volatile("" : "+v"(vb[s][j])::"memory");
                 it_tie(wt[s]);
-                if constexpr (SPLIT) { it_tie(vbd[s]); it_tie(bsv[s]); }
+                if constexpr (SPLIT && !LSB) { it_tie(vbd[s]); it_tie(bsv[s]); }
             }
         } else {
 #pragma unroll
@@ -296,7 +311,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
                     vb[s][2 * j + 1] = it_f32x2{piece[2], piece[3]};
                 }
                 wt[s] = vals[lo + (e < d ? e : 0)];
-                if constexpr (SPLIT) { vbd[s] = side[2 * (int64_t)idx[s]]; bsv[s] = side[2 * (int64_t)idx[s] + 1]; }   // {last feature, bias}
+                if constexpr (SPLIT && !LSB) { vbd[s] = side[2 * (int64_t)idx[s]]; bsv[s] = side[2 * (int64_t)idx[s] + 1]; }   // {last feature, bias}
+                if constexpr (LSB) { vbd[s] = cb; bsv[s] = 0.f; }
             }
         }
         }
@@ -528,7 +544,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void solve_iter_kernel(const int32_t*
             if (s < ns) {
                 const bool valid = EPS * s + 4 * wv + q < d;
                 float w = wt[s];
-                if constexpr (SPLIT) w -= bsv[s];           // the fixed side's bias comes with the row (RecModel/wmf_model.py:343)
+                if constexpr (LSB) w -= lsb_bias(vb[s][0]);  // ... rebuilt from the gathered row's own bits
+                else if constexpr (SPLIT) w -= bsv[s];      // the fixed side's bias comes with the row (RecModel/wmf_model.py:343)
                 // (vbd: the same on the 16 lanes of a group -- its uses count it once, see ybm / m0)
                 w = valid ? w : 0.f;
                 wt[s] = w;
@@ -748,19 +765,19 @@ int wmf_iter_dmax(int f, int ld, int split) {
     return 0;
 }
 
-template <int NW, int FPL, int NS, bool SPLIT, bool FULL, int OCC, bool DMA = false>
+template <int NW, int FPL, int NS, bool SPLIT, bool FULL, int OCC, bool DMA = false, bool LSB = false>
 static void it_launch(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* bounce_rows,
                       int32_t* bounce_count, unsigned long long* stats, const int4* info, hipStream_t st,
                       const int32_t* count_dev = nullptr, int bounce_stat = IT_STAT_BOUNCED) {
-    static const char* nm = wmf_kname("solve_iter_kernel<%d, %d, %d, %s, %s, %d, %s>", NW, FPL, NS, SPLIT ? "true" : "false",
-                                      FULL ? "true" : "false", OCC, DMA ? "true" : "false");
+    static const char* nm = wmf_kname(LSB ? "solve_iter_kernel<%d, %d, %d, %s, %s, %d, %s, true>" : "solve_iter_kernel<%d, %d, %d, %s, %s, %d, %s>", NW, FPL, NS,
+                                      SPLIT ? "true" : "false", FULL ? "true" : "false", OCC, DMA ? "true" : "false");
     using L = ItLds<NW, FPL>;
     // (DMA variant: exchange buffers, the ring of the next row's gathered rows, its weights and border / bias values)
     constexpr size_t dyn = DMA ? (size_t)L::EXCH * 4 + (size_t)NW * NS * (FPL / 4) * 1024 + NW * 768 : 0;
     static bool attr_set = false;
     if (DMA && !attr_set) {
-        (void)hipFuncSetAttribute((const void*)solve_iter_kernel<NW, FPL, NS, SPLIT, FULL, OCC, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        (void)hipFuncSetAttribute((const void*)solve_iter_kernel<NW, FPL, NS, SPLIT, FULL, OCC, DMA, LSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         attr_set = true;
     }
     // policy (environment overrides for experiments): start with the Neumann series while tau <= WMF_ITER_TAU (it converges
@@ -774,7 +791,7 @@ static void it_launch(const int32_t* rows, int64_t count, const float* V, const 
     // four rounds queued (rows differ in length); over a device-side list -- usually empty -- one round: every workgroup of a
     // launch has to be scheduled before it can find that out, 0.10 ms for 2048 workgroups of 72 KB of LDS
     const int64_t cap = count_dev ? resident : resident * 4;
-    WMF_LAUNCH(nm, (solve_iter_kernel<NW, FPL, NS, SPLIT, FULL, OCC, DMA>), dim3((unsigned)(count < cap ? count : cap)), dim3(64 * NW), dyn, st,
+    WMF_LAUNCH(nm, (solve_iter_kernel<NW, FPL, NS, SPLIT, FULL, OCC, DMA, LSB>), dim3((unsigned)(count < cap ? count : cap)), dim3(64 * NW), dyn, st,
                rows, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, tau_n, kap, kmax, eps * eps, stats, info, count_dev, bounce_stat);
 }
 
@@ -782,7 +799,7 @@ static void it_launch(const int32_t* rows, int64_t count, const float* V, const 
 // pairs of the split layout (V is then the packed body).  Rows that are not solved here are appended to bounce_rows.
 int wmf_launch_iter(const int32_t* rows, int64_t count, const float* V, const float* side, const int64_t* indptr,
                     const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* bounce_rows,
-                    int32_t* bounce_count, unsigned long long* stats, const void* info_v, hipStream_t st) {
+                    int32_t* bounce_count, unsigned long long* stats, const void* info_v, hipStream_t st, int lsb) {
     const int4* info = static_cast<const int4*>(info_v);     // NULL, or {first entry lo, hi, row id, entries} of rows[i] (wmf_plan_create)
     if (count <= 0) return 0;
     const bool split = side != nullptr;
@@ -802,6 +819,11 @@ int wmf_launch_iter(const int32_t* rows, int64_t count, const float* V, const fl
         // Stage 2: the four-wave LDS-DMA kernel over that list (count on the device; an empty list costs a few microseconds); what
         // IT hands back is the final list, bounce_rows[0 ..) / bounce_count[0], for the elimination kernels.
         int32_t* handed = bounce_rows + count;
+        if (split && lsb) {            // (the rolled coordinates with the bias in the rows' own bits: nothing fetched from the pairs)
+            it_launch<2, 8, 16, true, true, 2, false, true>(rows, count, V, side, indptr, indices, vals, f, ld, g, handed, bounce_count + 1, stats, info, st, nullptr, IT_STAT_STAGE1);
+            it_launch<4, 8, 8, true, true, 2, true, true>(handed, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, stats, nullptr, st, bounce_count + 1);
+            return 0;
+        }
         if (split) it_launch<2, 8, 16, true, true, 2>(rows, count, V, side, indptr, indices, vals, f, ld, g, handed, bounce_count + 1, stats, info, st, nullptr, IT_STAT_STAGE1);
         else it_launch<2, 8, 16, false, true, 2>(rows, count, V, side, indptr, indices, vals, f, ld, g, handed, bounce_count + 1, stats, info, st, nullptr, IT_STAT_STAGE1);
         if (split) it_launch<4, 8, 8, true, true, 2, true>(handed, count, V, side, indptr, indices, vals, f, ld, g, bounce_rows, bounce_count, stats, nullptr, st, bounce_count + 1);

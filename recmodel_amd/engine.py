@@ -134,9 +134,12 @@ class HipKernels:
     def plan_destroy(self, handle):
         self.lib.wmf_plan_destroy(handle)
 
-    def solve_rows(self, plan, V, bias_vec, indptr, indices, values, n, f, ld, g, fail):
-        _lib.check(self.lib.wmf_solve_rows(plan, _ptr(V), _ptr(bias_vec), _ptr(indptr), _ptr(indices), _ptr(values), n, f, ld,
-                                           _ptr(g), _ptr(fail), _stream()))
+    def solve_rows(self, plan, V, bias_vec, indptr, indices, values, n, f, ld, g, fail, flags=0):
+        _lib.check(self.lib.wmf_solve_rows_ex(plan, _ptr(V), _ptr(bias_vec), _ptr(indptr), _ptr(indices), _ptr(values), n, f, ld,
+                                              _ptr(g), _ptr(fail), int(flags), _stream()))
+
+    def rolled_layout_supported(self, f, ld):
+        return bool(self.lib.wmf_rolled_layout_supported(f, ld))
 
     def partial_row_floats(self, f):
         return int(self.lib.wmf_partial_row_floats(f))
@@ -450,6 +453,13 @@ class AlsEngine:
         # {last feature, bias} pairs [.., 2]; either way row ranges of the two tensors are what the kernels are given
         self.ldv = self.K.whitened_row_floats(self.f, self.ld, self.bias)
         self.split = self.ldv != self.ld
+        # rolled whitened coordinates with the bias in the body's last mantissa bits (include/wmf_hip.h, wmf_row_transform modes
+        # 3 / 4): the iteration kernels then fetch nothing from the pairs.  WMF_ROLLED=0 keeps the plain split layout.
+        self.rolled = bool(self.split and self.bias and os.environ.get("WMF_ROLLED", "1") != "0"
+                           and self.K.rolled_layout_supported(self.f, self.ld))
+        self.white_mode = 3 if self.rolled else self.bias           # set_col0_one of the whitening / of the un-whitening
+        self.unwhite_mode = 4 if self.rolled else False
+        self.solve_flags = 1 if self.rolled else 0
         self.V = {s: z(W * self.rpr[s], self.ldv) for s in self.n}
         self.bias_vec = {s: (z(W * self.rpr[s], 2) if self.split else z(W * self.rpr[s])) for s in self.n}
         self.G = z(self.f * self.f, dtype=torch.float64)
@@ -820,7 +830,7 @@ class AlsEngine:
         K.factorize(self.G, self.f, self.ld, self.gamma, self.W_white, self.W_unwhite, self.info, self.ws)
         V, bvec = self.V[fixed], self.bias_vec[fixed]
         if not self.exchange:
-            K.row_transform(self.X[fixed], self.n_local[fixed], self.f, self.ld, self.W_white, self.bias, V,
+            K.row_transform(self.X[fixed], self.n_local[fixed], self.f, self.ld, self.W_white, self.white_mode, V,
                             bvec if self.bias else None)
             return
         # whiten chunk by chunk, each as soon as ITS all-gather has landed: the passes over the early chunks run while
@@ -834,7 +844,7 @@ class AlsEngine:
                 pending[c - done].wait()
             rows = slice(start, stop)
             if stop > start:
-                K.row_transform(self.X[fixed][rows], stop - start, self.f, self.ld, self.W_white, self.bias, V[rows],
+                K.row_transform(self.X[fixed][rows], stop - start, self.f, self.ld, self.W_white, self.white_mode, V[rows],
                                 bvec[rows] if self.bias else None)
 
     def update(self, side):
@@ -845,9 +855,10 @@ class AlsEngine:
         self._wait(side)                             # nobody may still be reading the block that is about to be rewritten
         for c, ((lo, ln), csr) in enumerate(zip(self.chunk_bounds[side], self.csr_chunks[side])):
             g = self.g[side][lo: lo + ln]
-            K.solve_rows(csr._plan, self.V[fixed], bvec, csr.indptr, csr.indices, csr.values, ln, self.f, self.ld, g, self.fail)
+            K.solve_rows(csr._plan, self.V[fixed], bvec, csr.indptr, csr.indices, csr.values, ln, self.f, self.ld, g, self.fail,
+                         self.solve_flags)
             real = max(0, min(ln, self.n_local[side] - lo))
-            K.row_transform(g, real, self.f, self.ld, self.W_unwhite, False, self.factors[side][lo: lo + ln], None)
+            K.row_transform(g, real, self.f, self.ld, self.W_unwhite, self.unwhite_mode, self.factors[side][lo: lo + ln], None)
             self._publish(side, c)
         self.has_factors[side] = True
 
@@ -880,7 +891,7 @@ class AlsEngine:
                 pending[c - done].wait()
             rows = slice(start, stop)
             if stop > start:
-                K.row_transform(self.X[fixed][rows], stop - start, self.f, self.ld, self.W_white, self.bias, V[rows],
+                K.row_transform(self.X[fixed][rows], stop - start, self.f, self.ld, self.W_white, self.white_mode, V[rows],
                                 bvec[rows] if self.bias else None)
             K.accumulate_rows(V, bvec if self.bias else None, ptr, deg, idx, val, n, idx.numel(), self.f, self.ld,
                               self.partial_pipe[side], w_eff, slot_stride=C, slot_offset=c)
@@ -888,7 +899,7 @@ class AlsEngine:
         K.eliminate_rows(self.partial_pipe[side], n, self.f, self.ld, self.g[side], self.fail, self.scratch_rows, slots_per_row=C)
         if self._summed_system_failed(before):
             return self._redo_through_gather(side)
-        K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, False, self.factors[side], None)
+        K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, self.unwhite_mode, self.factors[side], None)
         self.has_factors[side] = True
         for c in range(len(self.chunk_bounds[side])):
             self._publish(side, c)
@@ -902,7 +913,7 @@ class AlsEngine:
         torch.distributed.all_reduce(self.G, group=self.group)
         K.factorize(self.G, self.f, self.ld, self.gamma, self.W_white, self.W_unwhite, self.info, self.ws)
         v_loc, b_loc = self.V[fixed][: self.rpr[fixed]], self.bias_vec[fixed][: self.rpr[fixed]]     # this rank's block only
-        K.row_transform(blk, self.n_local[fixed], self.f, self.ld, self.W_white, self.bias, v_loc, b_loc if self.bias else None)
+        K.row_transform(blk, self.n_local[fixed], self.f, self.ld, self.W_white, self.white_mode, v_loc, b_loc if self.bias else None)
         indptr, deg, idx, vals, w_eff = self.csr_red[side]
         self._wait(side)
         works = []
@@ -923,7 +934,7 @@ class AlsEngine:
         K.eliminate_rows(self.partial_mine[side], self.rpr[side], self.f, self.ld, self.g[side], self.fail, self.scratch_rows)
         if self._summed_system_failed(before):
             return self._redo_through_gather(side)
-        K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, False, self.factors[side], None)
+        K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, self.unwhite_mode, self.factors[side], None)
         self.has_factors[side] = True
         for c in range(len(self.chunk_bounds[side])):
             self._publish(side, c)
@@ -958,7 +969,7 @@ class AlsEngine:
         K, W = self.K, self.world
         fixed = self._other(side)
         self._ensure_gathered(fixed)
-        K.row_transform(self.X[fixed], self.X[fixed].shape[0], self.f, self.ld, self.W_white, self.bias, self.V[fixed],
+        K.row_transform(self.X[fixed], self.X[fixed].shape[0], self.f, self.ld, self.W_white, self.white_mode, self.V[fixed],
                         self.bias_vec[fixed] if self.bias else None)
         self.update(side)
 
@@ -980,7 +991,7 @@ class AlsEngine:
         self.prepare(fixed)
         c = self.csr[side]
         K.spmm_rows(self.V[fixed], c.indptr, c.indices, c.values, c.n_rows, self.f, self.ld, self.g[side])
-        K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, False, self.factors[side], None)
+        K.row_transform(self.g[side], self.n_local[side], self.f, self.ld, self.W_unwhite, self.unwhite_mode, self.factors[side], None)
         self.has_factors[side] = True
         for c in range(len(self.chunk_bounds[side])):
             self._publish(side, c)

@@ -50,8 +50,16 @@ class NumpyKernels:
         W_white.numpy()[:, :f] = Linv.T
         W_unwhite.numpy()[:, :f] = Linv
 
+    def rolled_layout_supported(self, f, ld):
+        """wmf_rolled_layout_supported: bias models with a 128-float body."""
+        return f == 129 and self.whitened_row_floats(f, ld, True) == f - 1
+
     def row_transform(self, inp, m, f, ld, W, set_col0_one, out, col0_out):
         x = inp.numpy()[:m, :f].astype(np.float64).copy()
+        mode = int(set_col0_one)
+        if mode == 4:                                   # the input is in rolled coordinates: position c holds feature c + 1 (mod f)
+            x = np.roll(x, 1, axis=1)
+            set_col0_one = False
         split = set_col0_one and self.whitened_row_floats(f, ld, True) == f - 1
         if set_col0_one:
             if split:
@@ -60,6 +68,8 @@ class NumpyKernels:
                 col0_out.numpy()[:m] = inp.numpy()[:m, 0]
             x[:, 0] = 1.0
         y = x @ W.numpy()[:, :f].astype(np.float64)
+        if mode == 3:                                   # written in rolled coordinates (the stand-in leaves the mantissa bits alone:
+            y = np.roll(y, -1, axis=1)                  # its solve_rows reads the bias from the pairs)
         if split:
             out.numpy().reshape(-1, f - 1)[:m] = y[:, : f - 1]
             col0_out.numpy().reshape(-1, 2)[:m, 0] = y[:, f - 1]
@@ -77,7 +87,7 @@ class NumpyKernels:
     def plan_destroy(self, handle):
         pass
 
-    def solve_rows(self, plan, V, bias_vec, indptr, indices, values, n, f, ld, g, fail):
+    def solve_rows(self, plan, V, bias_vec, indptr, indices, values, n, f, ld, g, fail, flags=0):
         v, b = self._whitened(V, bias_vec, f, ld)
         ip, ix, w = indptr.numpy(), indices.numpy(), values.numpy().astype(np.float64)
         out = g.numpy()

@@ -142,6 +142,40 @@ def test_iteration_off_gives_the_same_rows():
     assert rel.max() <= 4.2e-6, rel.max()                         # measured 1.4e-6
 
 
+def test_rolled_coordinates_carry_the_bias_in_the_rows_own_bits(monkeypatch):
+    """k = 128 with biases (include/wmf_hip.h, wmf_row_transform modes 3 / 4, wmf_solve_rows_ex): the whitened side is kept in
+    coordinates rolled by one, so that its border feature is the constant 1 / L00, and the 32 bits of a row's bias replace the last
+    mantissa bit of body positions 8 j, 8 j + 1 -- the iteration kernels then fetch nothing from the {border, bias} pairs.  Checked:
+    the engine takes that path by default; every border value is the same number; the bits in the body ARE the bias, bit for bit;
+    the rows agree with the plain split layout (WMF_ROLLED=0) to float32 rounding and with the float64 oracle at the usual gate."""
+    eng, indptr, indices, w, Y = _engine(3000, 250_000, 128, True, 33, 120, 1.0, 777)
+    assert eng.rolled and eng.white_mode == 3 and eng.solve_flags == 1
+    eng.half_step("users")
+    torch.cuda.synchronize()
+    st = eng.iter_stats("users")
+    assert int(st[0]) >= 2900, st                                   # the rows went through the iteration kernel
+    body = eng.V["items"].cpu().numpy().reshape(-1, 128)[: Y.shape[0]]
+    pairs = eng.bias_vec["items"].cpu().numpy().reshape(-1, 2)[: Y.shape[0]]
+    assert np.unique(pairs[:, 0]).size == 1                         # the border feature: one number for every row
+    np.testing.assert_array_equal(pairs[:, 1], Y[:, 0].astype(np.float32))
+    bits = body.view(np.uint32) & 1
+    rebuilt = np.zeros(Y.shape[0], dtype=np.uint32)
+    for j in range(16):
+        rebuilt |= (bits[:, 8 * j] << np.uint32(2 * j)) | (bits[:, 8 * j + 1] << np.uint32(2 * j + 1))
+    np.testing.assert_array_equal(rebuilt.view(np.float32), pairs[:, 1])
+    rolled = eng.factors["users"].cpu().numpy()[:3000, : eng.f].copy()
+    _check(eng, indptr, indices, w, Y, np.arange(0, 3000, 23), 1.5e-5, 7e-6, "rolled[k=128,bias=1]")
+    monkeypatch.setenv("WMF_ROLLED", "0")
+    plain_eng, *_ = _engine(3000, 250_000, 128, True, 33, 120, 1.0, 777)
+    assert not plain_eng.rolled
+    plain_eng.half_step("users")
+    torch.cuda.synchronize()
+    plain = plain_eng.factors["users"].cpu().numpy()[:3000, : eng.f]
+    diff = np.linalg.norm(rolled - plain, axis=1) / np.linalg.norm(plain, axis=1)
+    record_error("rolled_vs_plain[k=128,bias=1]", worst_row=float(diff.max()))
+    assert diff.max() <= 4.2e-6, diff.max()
+
+
 @pytest.mark.parametrize("k,bias", [(64, False), (64, True), (100, False), (128, True)])
 def test_float64_iteration_against_the_float64_oracle(k, bias):
     """The float64 form of the iteration (csrc/wmf_iter64.hip, inside wmf_half_step_f64 -- the reference's cores > 1 variants,

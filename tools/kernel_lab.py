@@ -57,13 +57,13 @@ for fl in flags:
     lib.wmf_debug_set_flags(fl)
     lib.wmf_profile_enable(0)
     for _ in range(2):
-        _lib.check(lib.wmf_solve_rows(c._plan, _ptr(eng.V[fixed]), _ptr(eng.bias_vec[fixed]) if bias else None, _ptr(c.indptr),
-                                      _ptr(c.indices), _ptr(c.values), c.n_rows, eng.f, eng.ld, _ptr(eng.g[side]), _ptr(eng.fail), _stream()))
+        _lib.check(lib.wmf_solve_rows_ex(c._plan, _ptr(eng.V[fixed]), _ptr(eng.bias_vec[fixed]) if bias else None, _ptr(c.indptr),
+                                      _ptr(c.indices), _ptr(c.values), c.n_rows, eng.f, eng.ld, _ptr(eng.g[side]), _ptr(eng.fail), eng.solve_flags, _stream()))
     torch.cuda.synchronize()
     lib.wmf_profile_enable(1)
     for _ in range(reps):
-        _lib.check(lib.wmf_solve_rows(c._plan, _ptr(eng.V[fixed]), _ptr(eng.bias_vec[fixed]) if bias else None, _ptr(c.indptr),
-                                      _ptr(c.indices), _ptr(c.values), c.n_rows, eng.f, eng.ld, _ptr(eng.g[side]), _ptr(eng.fail), _stream()))
+        _lib.check(lib.wmf_solve_rows_ex(c._plan, _ptr(eng.V[fixed]), _ptr(eng.bias_vec[fixed]) if bias else None, _ptr(c.indptr),
+                                      _ptr(c.indices), _ptr(c.values), c.n_rows, eng.f, eng.ld, _ptr(eng.g[side]), _ptr(eng.fail), eng.solve_flags, _stream()))
     torch.cuda.synchronize()
     lib.wmf_profile_enable(0)
     print(f"flags={fl}: " + ", ".join(f"{nm}={ms / reps:.3f}ms/{n // reps}" for nm, _, ms, n, _, _ in _lib.profile_table(lib)))
