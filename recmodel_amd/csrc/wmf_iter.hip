@@ -770,8 +770,8 @@ static void it_launch(const int32_t* rows, int64_t count, const float* V, const 
                       const int32_t* indices, const float* vals, int f, int ld, float* g, int32_t* bounce_rows,
                       int32_t* bounce_count, unsigned long long* stats, const int4* info, hipStream_t st,
                       const int32_t* count_dev = nullptr, int bounce_stat = IT_STAT_BOUNCED) {
-    static const char* nm = wmf_kname(LSB ? "solve_iter_kernel<%d, %d, %d, %s, %s, %d, %s, true>" : "solve_iter_kernel<%d, %d, %d, %s, %s, %d, %s>", NW, FPL, NS,
-                                      SPLIT ? "true" : "false", FULL ? "true" : "false", OCC, DMA ? "true" : "false");
+    static const char* nm = wmf_kname("solve_iter_kernel<%d, %d, %d, %s, %s, %d, %s, %s>", NW, FPL, NS, SPLIT ? "true" : "false",
+                                      FULL ? "true" : "false", OCC, DMA ? "true" : "false", LSB ? "true" : "false");      // (as rocprofv3 prints it)
     using L = ItLds<NW, FPL>;
     // (DMA variant: exchange buffers, the ring of the next row's gathered rows, its weights and border / bias values)
     constexpr size_t dyn = DMA ? (size_t)L::EXCH * 4 + (size_t)NW * NS * (FPL / 4) * 1024 + NW * 768 : 0;
