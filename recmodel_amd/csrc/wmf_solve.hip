@@ -112,6 +112,23 @@ __device__ __forceinline__ void low_split8(const float4& a, const float4& b, low
     hi = __builtin_bit_cast(low_f16x8, wmf_u32x4{s0[0], s0[1], s1[0], s1[1]});
     lo = __builtin_bit_cast(low_f16x8, wmf_u32x4{s0[2], s0[3], s1[2], s1[3]});
 }
+// bstride = 3: the rolled coordinates of wmf_row_transform mode 3 (include/wmf_hip.h) -- the border feature is biasv[0] for every
+// row and the 32 bits of an entry's bias are the last mantissa bits of its body features 8 j, 8 j + 1 (j < 16).  In the X6 piece
+// order lane (r, q) holds piece 2 j = 8 c + 2 q of entry r for c = 0 .. 3, i.e. j = 4 c + q: eight of the bits; the entry's four lanes
+// (r, r + 16, r + 32, r + 48) OR theirs together.  pieces[2 c] = piece 8 c + 2 q.
+template <class P>
+__device__ __forceinline__ float wmf_lsb_bias(const P& pieces, int q) {
+    unsigned b = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned two = (__builtin_bit_cast(unsigned, pieces[2 * c].x) & 1u) | ((__builtin_bit_cast(unsigned, pieces[2 * c].y) & 1u) << 1);
+        b |= two << (8 * c + 2 * q);
+    }
+    b |= (unsigned)__shfl_xor((int)b, 16);
+    b |= (unsigned)__shfl_xor((int)b, 32);
+    return __builtin_bit_cast(float, b);
+}
+
 template <int NCH, int NSETS, bool BLK, bool X6 = false>
 __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 4) ? 5 : 1)) void solve_low_kernel(const int32_t* __restrict__ rows, int64_t count,
                                                         const float* __restrict__ V, const float* __restrict__ biasv,
@@ -135,7 +152,8 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
     const int d = __builtin_amdgcn_readfirstlane((int)(indptr[u + 1] - lo));
     const int r = lane & 15, q = lane >> 4;
     const int nch = ld >> 2;
-    const int vch = bstride == 2 ? nch - 1 : nch;   // 16-byte pieces of a stored row of V
+    const int vch = bstride >= 2 ? nch - 1 : nch;   // 16-byte pieces of a stored row of V
+    const float cb = bstride == 3 ? biasv[0] : 0.f; // (3) every row's border value
 
     // All loads are unconditional and clamped to a stored entry (under a per-lane select hipcc sinks the load
     // into a branch and waits for each in turn).  Slots j >= d read the factor row of entry 0 -- real, finite
@@ -170,6 +188,9 @@ __global__ __launch_bounds__(256, (NSETS == 1 && NCH <= 9) ? 6 : ((X6 && NCH <= 
             if (bstride == 2) {                          // split layout: f = 4 (nch - 1) + 1, the last piece is { feature f - 1, bias, 0, 0 }
                 const float2 sd = reinterpret_cast<const float2*>(biasv)[idx];
                 v = make_float4(sd.x, sd.y, 0.f, 0.f);
+            } else if (bstride == 3) {                   // ... and neither half of it is fetched
+                if constexpr (X6 && NCH == 9) v = make_float4(cb, wmf_lsb_bias(x[s], q), 0.f, 0.f);
+                else v = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 v = (vrow - q)[last_c];
             }
@@ -426,7 +447,8 @@ __global__ __launch_bounds__(256, NCH <= 9 ? 6 : 1) void solve_pair_kernel(const
     constexpr bool TAIL = X6 && (NCH & 1);           // X6 (solve_low_kernel): whole 32-feature chunks and at most one more piece
     const int last_c = TAIL ? nch - 1 : min(4 * (NCH - 1) + q, nch - 1);
     const float last_m = TAIL ? (q == 0 ? 1.f : 0.f) : ((4 * (NCH - 1) + q < nch) ? 1.f : 0.f);
-    const float4* vrow = Vq + (int64_t)idx * (bstride == 2 ? nch - 1 : nch);
+    const float4* vrow = Vq + (int64_t)idx * (bstride >= 2 ? nch - 1 : nch);
+    const float cb = bstride == 3 ? biasv[0] : 0.f;  // (3) every row's border value (solve_low_kernel)
     if constexpr (X6) {
 #pragma unroll
         for (int t = 0; t < NCH - (TAIL ? 1 : 0); ++t) x[t] = (vrow - q)[8 * (t >> 1) + 2 * q + (t & 1)];
@@ -439,6 +461,9 @@ __global__ __launch_bounds__(256, NCH <= 9 ? 6 : 1) void solve_pair_kernel(const
         if (bstride == 2) {                              // split layout: the last piece from the {last feature, bias} pair (solve_low_kernel)
             const float2 sd = reinterpret_cast<const float2*>(biasv)[idx];
             v = make_float4(sd.x, sd.y, 0.f, 0.f);
+        } else if (bstride == 3) {
+            if constexpr (X6 && NCH == 9) v = make_float4(cb, wmf_lsb_bias(x, q), 0.f, 0.f);
+            else v = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
             v = (vrow - q)[last_c];
         }
@@ -559,18 +584,18 @@ __global__ __launch_bounds__(256) void solve_general_kernel(const int32_t* __res
                 const int j = e / nch, c = e % nch;
                 const int idx = indices[lo + base + j];
                 float4 v;
-                if (bstride == 2 && c == nch - 1) {
+                if (bstride >= 2 && c == nch - 1) {
                     const float2 sd = reinterpret_cast<const float2*>(biasv)[idx];
                     v = make_float4(sd.x, sd.y, 0.f, 0.f);
                 } else {
-                    v = reinterpret_cast<const float4*>(V + (int64_t)idx * (bstride == 2 ? ld - 4 : ld))[c];
+                    v = reinterpret_cast<const float4*>(V + (int64_t)idx * (bstride >= 2 ? ld - 4 : ld))[c];
                 }
                 *reinterpret_cast<float4*>(&Vs[j * LDV + 4 * c]) = v;
             }
             if (tid < nrow) {
                 const int idx = indices[lo + base + tid];
                 float wj = vals[lo + base + tid];
-                if (biasv) wj -= biasv[bstride == 2 ? 2 * (int64_t)idx + 1 : (int64_t)idx];
+                if (biasv) wj -= biasv[bstride >= 2 ? 2 * (int64_t)idx + 1 : (int64_t)idx];
                 ws[tid] = wj;
             }
             __syncthreads();
@@ -720,6 +745,7 @@ static void launch_low(const wmf_plan* pl, const float* V, const float* biasv, i
     // (debug flag 524288: f32 MFMAs everywhere)
     constexpr bool X6_OK = (NCH % 2 == 0) || (NCH >= 3);
     const bool x6 = X6_OK && !(wmf_debug_flags & 524288) && ((NCH % 2 == 0) ? (ld % 32 == 0) : (last1 && ld == 16 * (NCH - 1) + 4));   // (last1: f = ld - 3, one feature in the last piece)
+    if (bstride == 3 && !(x6 && NCH == 9)) bstride = 2;        // (the bias is rebuilt from the row in the X6 piece order only: elsewhere the pairs are read)
 #define WMF_LOW_LAUNCH(KERNEL, NAME, ROWS, COUNT, GRID)                                                                   \
     do {                                                                                                                  \
         static const char* nm_ = NAME;                                                                                     \
@@ -825,7 +851,7 @@ int wmf_launch_solve(const wmf_plan* pl, const float* V, const float* biasv, con
     const float* side = nullptr;
     if (biasv && wmf_split_layout(f, ld)) {                            // split layout: V is the packed body, biasv the pairs
         side = biasv;
-        bstride = 2;
+        bstride = (pl->rolled && f == 129) ? 3 : 2;                     // (3: wmf_solve_rows_ex(WMF_SOLVE_ROLLED): the low-row kernels rebuild the bias from the row)
     } else if (biasv) {                                                // other widths: fold the biases into the weights once
         if (!pl->w_eff) return -3;                                     // (plan latched the split layout, this call is not in it)
         wmf_launch_bias_adjust(vals, indices, biasv, nnz, pl->w_eff, st);   // (w_eff: allocated by wmf_plan_create(bias = 1))
