@@ -23,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None, dim=6):
+def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None, dim=6, sizes=(203, 57)):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -33,11 +33,12 @@ def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None,
         from oracle import wmf_oracle as orc
         from recmodel_amd import synth
         from recmodel_amd.engine import AlsEngine
-        n_users, n_items = 203, 57                   # not multiples of the world size: padding rows exist
+        n_users, n_items = sizes                     # not multiples of the world size: padding rows exist
         indptr, indices, counts = synth.make_counts(n_users, n_items, 5, seed=11)
         values = (10 * torch.log(1 + counts)).to(torch.float32)
         eng = AlsEngine(n_users, n_items, dim, bias, 0.1, device="cpu", kernels=NumpyKernels(), chunks=4, reduce_mode=reduce_mode, pipe_mode=pipe_mode)
-        assert eng.split == (bias and dim == 16)     # k = 16 with biases: packed body + {last feature, bias} pairs
+        assert eng.split == (bias and dim in (16, 128))     # k = 16 m with biases: packed body + {last feature, bias} pairs
+        assert eng.rolled == (bias and dim == 128 and os.environ.get("WMF_ROLLED", "1") != "0")   # ... in rolled coordinates at k = 128 (wmf_row_transform modes 3 / 4)
         if reduce_mode:
             assert eng.reduce == {"users": False, "items": True}             # the smaller side travels as partial systems
         assert len(eng.csr_chunks) == 0 and len(eng.chunk_bounds["users"]) == 4
@@ -66,16 +67,16 @@ def _worker(rank, world, port, bias, out_path, reduce_mode=None, pipe_mode=None,
 
 @pytest.mark.parametrize("bias,reduce_mode,pipe_mode", [(False, None, None), (True, None, None), (False, True, None),
                                                         (True, True, None), (False, False, True), (True, False, True)])
-def test_two_rank_als_matches_single_process_oracle(tmp_path, bias, reduce_mode, pipe_mode, dim=6):
+def test_two_rank_als_matches_single_process_oracle(tmp_path, bias, reduce_mode, pipe_mode, dim=6, sizes=(203, 57)):
     """reduce_mode=True: the item half step accumulates partial systems on every rank and reduce-scatters them
     (here an all-reduce + slice: gloo has no reduce-scatter); the user block is then only gathered on demand.
     pipe_mode=True: both half steps accumulate over each gathered chunk of the fixed side as it arrives."""
     from oracle import wmf_oracle as orc
     from recmodel_amd import synth
     out = str(tmp_path / "out.npz")
-    mp.spawn(_worker, args=(2, _free_port(), bias, out, reduce_mode, pipe_mode, dim), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), bias, out, reduce_mode, pipe_mode, dim, sizes), nprocs=2, join=True)
     got = np.load(out)
-    n_users, n_items = 203, 57
+    n_users, n_items = sizes
     indptr, indices, counts = synth.make_counts(n_users, n_items, 5, seed=11)
     raw = synth.to_scipy(indptr, indices, counts, (n_users, n_items))
     C = raw.astype(np.float64)
@@ -86,8 +87,9 @@ def test_two_rank_als_matches_single_process_oracle(tmp_path, bias, reduce_mode,
     for _ in range(2):
         users = step(items, C, 0.1)
         items = step(users, CT, 0.1)
-    np.testing.assert_allclose(got["users"], users, rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(got["items"], items, rtol=2e-4, atol=2e-5)
+    atol = 2e-5 if dim < 64 else 5e-5        # (f = 129: the float32 whitened side of the stand-in costs more, rolled or not)
+    np.testing.assert_allclose(got["users"], users, rtol=2e-4, atol=atol)
+    np.testing.assert_allclose(got["items"], items, rtol=2e-4, atol=atol)
     mse = orc.eval_prec(users, items, raw, bias)
     assert abs(got["sums"][0] / got["sums"][2] - mse) <= 1e-4 * mse
     assert got["sums"][2] == raw.nnz
@@ -99,6 +101,14 @@ def test_two_ranks_split_layout_of_the_whitened_side(tmp_path, reduce_mode, pipe
     pairs (include/wmf_hip.h, wmf_row_transform); the engine sizes and slices the two arrays accordingly in the gather,
     reduce and pipelined modes (row ranges per chunk, this rank's block only in reduce mode, no w_eff pass)."""
     test_two_rank_als_matches_single_process_oracle(tmp_path, True, reduce_mode, pipe_mode, dim=16)
+
+
+@pytest.mark.parametrize("reduce_mode,pipe_mode", [(None, None), (True, None), (False, True)])
+def test_two_ranks_rolled_coordinates_of_the_whitened_side(tmp_path, reduce_mode, pipe_mode):
+    """k = 128 with biases (f = 129): the engine whitens with wmf_row_transform mode 3, solves with WMF_SOLVE_ROLLED and un-whitens
+    with mode 4 (include/wmf_hip.h) in the gather, reduce and pipelined modes alike -- a permutation of the whitened features that
+    must not show in the factors."""
+    test_two_rank_als_matches_single_process_oracle(tmp_path, True, reduce_mode, pipe_mode, dim=128, sizes=(1203, 457))
 
 
 @pytest.mark.parametrize("mode", ["gather", "reduce", "pipe"])
